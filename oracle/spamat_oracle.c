@@ -1,0 +1,354 @@
+/*
+ * oracle/spamat_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's SpaMat / SpaVar CUDA kernels, one
+ * "thread index" at a time, in the reference's own loop order.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call
+ * this file; the product path (decnet_amd/) never does.
+ *
+ * PARITY STATUS: the reference ships no tests, no golden vectors and no CPU
+ * path for these kernels, and nvcc is not in this image, so the reference
+ * itself cannot be run here: "parity unpinned" by reference execution.  It is
+ * pinned instead by (1) this literal transliteration, (2) an independent
+ * vectorised torch restatement + autograd cross-check in tests/, and (3)
+ * known-answer quirk cases.
+ *
+ * Reference (all under /root/reference/modules/):
+ *   get_max_cost                  SparseMatching/src/SM_kernel.cu:22-60
+ *   sparse_matching_forward       SparseMatching/src/SM_kernel.cu:76-125
+ *   sparse_matching_ref_backward  SparseMatching/src/SM_kernel.cu:143-195
+ *   sparse_matching_tar_backward  SparseMatching/src/SM_kernel.cu:300-355
+ *   host launchers                SparseMatching/src/SM_kernel.cu:359-429
+ *   sparse_var_forward            SparseVar/src/SV_kernel.cu:76-124
+ *   sparse_var_ref_backward       SparseVar/src/SV_kernel.cu:142-195
+ *   sparse_var_tar_backward       SparseVar/src/SV_kernel.cu:215-271
+ *   sparse_var_dis_backward       SparseVar/src/SV_kernel.cu:275-325
+ *   host launchers                SparseVar/src/SV_kernel.cu:329-410
+ *
+ * Floating-point contraction.  nvcc's default (-fmad=true) fuses `acc += a*b`
+ * into one FMA, so the reference binary evaluates the channel dot product as a
+ * c-ordered fmaf chain.  This file is compiled with -ffp-contract=off and
+ * spells the fused sites out: MAC(acc,a,b) is fmaf when ORACLE_FMA=1 (default,
+ * what the CUDA binary does) and a rounded mul + add when ORACLE_FMA=0 (the
+ * source as written).  tests/ check that both agree within the stated
+ * tolerance, so no conclusion depends on which one nvcc picked.
+ *
+ * Caller contract, as in functions/SpaMat.py:25-27,42-43: every output buffer
+ * is zero-filled by the caller; entries the kernels skip stay 0.
+ */
+#include <math.h>
+#include <stddef.h>
+
+#ifndef ORACLE_FMA
+#define ORACLE_FMA 1
+#endif
+
+#if ORACLE_FMA
+#define MAC(acc, a, b) fmaf((a), (b), (acc))
+#else
+#define MAC(acc, a, b) ((acc) + (a) * (b))
+#endif
+
+#ifdef _OPENMP
+#define PARALLEL_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define PARALLEL_FOR
+#endif
+
+/* channel dot product: SM_kernel.cu:52-55 (and every copy of that loop) */
+static inline float dot_c(const float *l, const float *r, int channel, long step) {
+    float cost = 0.f;
+    for (int cha = 0; cha < channel; cha++)
+        cost = MAC(cost, l[cha * step], r[cha * step]);
+    return cost;
+}
+
+/* SM_kernel.cu:22-60 (duplicated at SV_kernel.cu:22-60) */
+static void get_max_cost(long num_ele, int channel, int height, int width, int max_disp,
+                         const float *ref, const float *tar, const float *rmask,
+                         const float *tmask, float *max_cost_data) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        if (rmask[index] == 0) continue;
+        long id_batch = index / width / height;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3d = id_batch * channel * step + id_height * width + id_width;
+        int cur_max_disp = id_width - max_disp + 1 >= 0 ? max_disp : (int)id_width + 1;
+        float max_cost = 0.000001f;
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            if (tmask[index - disp] == 0) continue;
+            float cost = dot_c(ref + base_3d, tar + base_3d - disp, channel, step);
+            if (max_cost < cost) max_cost = cost;
+        }
+        max_cost_data[index] = max_cost;
+    }
+}
+
+/* SM_kernel.cu:76-125 */
+static void sparse_matching_forward(long num_ele, int channel, int height, int width, int max_disp,
+                                    const float *ref, const float *tar, const float *rmask,
+                                    const float *tmask, const float *max_cost_data,
+                                    float *output, float *sum_sim) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        if (rmask[index] == 0) continue;
+        long id_batch = index / width / height;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3d = id_batch * channel * step + id_height * width + id_width;
+        int cur_max_disp = id_width - max_disp + 1 >= 0 ? max_disp : (int)id_width + 1;
+        float sum_similarity = 0.000001f, sum_disp = 0.000001f, tmp_sim;
+        float max_cost = max_cost_data[index];
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            if (tmask[index - disp] == 0) continue;
+            float cost = dot_c(ref + base_3d, tar + base_3d - disp, channel, step);
+            tmp_sim = expf(cost - max_cost);
+            sum_disp = MAC(sum_disp, tmp_sim, (float)disp);
+            sum_similarity += tmp_sim;
+        }
+        sum_sim[index] = sum_similarity;
+        output[index] = sum_disp / sum_similarity;
+    }
+}
+
+/* SM_kernel.cu:143-195; one "thread" per (b,c,y,x), full C-dot redone per thread */
+static void sparse_matching_ref_backward(long num_ele, int channel, int height, int width, int max_disp,
+                                         const float *ref, const float *tar, const float *rmask,
+                                         const float *tmask, const float *output,
+                                         const float *sum_sim, const float *max_cost_data,
+                                         const float *grad_output, float *grad_ref) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        long id_batch = index / width / height / channel;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3D = index;
+        long cost_3D = id_batch * channel * step + id_height * width + id_width;
+        long base_2D = id_batch * step + id_height * width + id_width;
+        if (rmask[base_2D] == 0) continue;
+        int cur_max_disp = id_width - max_disp + 1 >= 0 ? max_disp : (int)id_width + 1;
+        float tmp_grad = 0, tmp_sim = 0;
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            if (tmask[base_2D - disp] == 0) continue;
+            float cost = dot_c(ref + cost_3D, tar + cost_3D - disp, channel, step);
+            tmp_sim = cost - max_cost_data[base_2D];
+            tmp_sim = expf(tmp_sim);
+            /* tmp_grad += tmp_sim * tar[base_3D-disp] * (disp - out) */
+            tmp_grad = MAC(tmp_grad, tmp_sim * tar[base_3D - disp], (float)disp - output[base_2D]);
+        }
+        grad_ref[base_3D] = grad_output[base_2D] * tmp_grad / sum_sim[base_2D];
+    }
+}
+
+/* SM_kernel.cu:300-355 */
+static void sparse_matching_tar_backward(long num_ele, int channel, int height, int width, int max_disp,
+                                         const float *ref, const float *tar, const float *rmask,
+                                         const float *tmask, const float *output,
+                                         const float *sum_sim, const float *max_cost_data,
+                                         const float *grad_output, float *grad_tar) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        long id_batch = index / width / height / channel;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3D = index;
+        long cost_3D = id_batch * channel * step + id_height * width + id_width;
+        long base_2D = id_batch * step + id_height * width + id_width;
+        if (tmask[base_2D] == 0) continue;
+        int cur_max_disp = id_width + max_disp <= width ? max_disp : width - (int)id_width;
+        float tmp_grad = 0, tmp_sim = 0;
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            long s2 = base_2D + disp, s3 = base_3D + disp, c3 = cost_3D + disp;
+            if (rmask[s2] == 0) continue;
+            float cost = dot_c(ref + c3, tar + cost_3D, channel, step);
+            tmp_sim = cost - max_cost_data[s2];
+            tmp_sim = expf(tmp_sim);
+            /* tmp_grad += g * e * L * (disp-out) / S   (left-to-right, then fused add) */
+            float t = grad_output[s2] * tmp_sim * ref[s3] * ((float)disp - output[s2]) / sum_sim[s2];
+            tmp_grad += t;
+        }
+        grad_tar[index] = tmp_grad;
+    }
+}
+
+/* SV_kernel.cu:76-124 */
+static void sparse_var_forward(long num_ele, int channel, int height, int width, int max_disp,
+                               const float *ref, const float *tar, const float *rmask,
+                               const float *tmask, const float *disparity,
+                               const float *max_cost_data, float *output, float *sum_sim) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        if (rmask[index] == 0) continue;
+        long id_batch = index / width / height;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3d = id_batch * channel * step + id_height * width + id_width;
+        int cur_max_disp = id_width - max_disp + 1 >= 0 ? max_disp : (int)id_width + 1;
+        float sum_similarity = 0.000001f, sum_disp = 0.000001f, tmp_sim;
+        float max_cost = max_cost_data[index];
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            if (tmask[index - disp] == 0) continue;
+            float cost = dot_c(ref + base_3d, tar + base_3d - disp, channel, step);
+            tmp_sim = expf(cost - max_cost);
+            float dd = (float)disp - disparity[index];
+            sum_disp = MAC(sum_disp, tmp_sim * dd, dd);
+            sum_similarity += tmp_sim;
+        }
+        sum_sim[index] = sum_similarity;
+        output[index] = sum_disp / sum_similarity;
+    }
+}
+
+/* SV_kernel.cu:142-195 */
+static void sparse_var_ref_backward(long num_ele, int channel, int height, int width, int max_disp,
+                                    const float *ref, const float *tar, const float *rmask,
+                                    const float *tmask, const float *disparity, const float *output,
+                                    const float *sum_sim, const float *max_cost_data,
+                                    const float *grad_output, float *grad_ref) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        long id_batch = index / width / height / channel;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3D = index;
+        long cost_3D = id_batch * channel * step + id_height * width + id_width;
+        long base_2D = id_batch * step + id_height * width + id_width;
+        if (rmask[base_2D] == 0) continue;
+        int cur_max_disp = id_width - max_disp + 1 >= 0 ? max_disp : (int)id_width + 1;
+        float tmp_grad = 0, tmp_sim = 0;
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            if (tmask[base_2D - disp] == 0) continue;
+            float cost = dot_c(ref + cost_3D, tar + cost_3D - disp, channel, step);
+            tmp_sim = cost - max_cost_data[base_2D];
+            tmp_sim = expf(tmp_sim);
+            float dd = (float)disp - disparity[base_2D];
+            tmp_grad = MAC(tmp_grad, tmp_sim * tar[base_3D - disp], MAC(-output[base_2D], dd, dd));
+        }
+        grad_ref[base_3D] = grad_output[base_2D] * tmp_grad / sum_sim[base_2D];
+    }
+}
+
+/* SV_kernel.cu:215-271 */
+static void sparse_var_tar_backward(long num_ele, int channel, int height, int width, int max_disp,
+                                    const float *ref, const float *tar, const float *rmask,
+                                    const float *tmask, const float *disparity, const float *output,
+                                    const float *sum_sim, const float *max_cost_data,
+                                    const float *grad_output, float *grad_tar) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        long id_batch = index / width / height / channel;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3D = index;
+        long cost_3D = id_batch * channel * step + id_height * width + id_width;
+        long base_2D = id_batch * step + id_height * width + id_width;
+        if (tmask[base_2D] == 0) continue;
+        int cur_max_disp = id_width + max_disp <= width ? max_disp : width - (int)id_width;
+        float tmp_grad = 0, tmp_sim = 0;
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            long s2 = base_2D + disp, s3 = base_3D + disp, c3 = cost_3D + disp;
+            if (rmask[s2] == 0) continue;
+            float cost = dot_c(ref + c3, tar + cost_3D, channel, step);
+            tmp_sim = cost - max_cost_data[s2];
+            tmp_sim = expf(tmp_sim);
+            float dd = (float)disp - disparity[s2];
+            float t = grad_output[s2] * tmp_sim * ref[s3] * MAC(-output[s2], dd, dd) / sum_sim[s2];
+            tmp_grad += t;
+        }
+        grad_tar[index] = tmp_grad;
+    }
+}
+
+/* SV_kernel.cu:275-325 */
+static void sparse_var_dis_backward(long num_ele, int channel, int height, int width, int max_disp,
+                                    const float *ref, const float *tar, const float *rmask,
+                                    const float *tmask, const float *disparity,
+                                    const float *sum_sim, const float *max_cost_data,
+                                    const float *grad_output, float *grad_disparity) {
+    PARALLEL_FOR
+    for (long index = 0; index < num_ele; index++) {
+        if (rmask[index] == 0) continue;
+        long id_batch = index / width / height;
+        long id_height = index / width % height;
+        long id_width = index % width;
+        long step = (long)width * height;
+        long base_3d = id_batch * channel * step + id_height * width + id_width;
+        int cur_max_disp = id_width - max_disp + 1 >= 0 ? max_disp : (int)id_width + 1;
+        float tmp_grad = 0, tmp_sim = 0;
+        for (int disp = 0; disp < cur_max_disp; disp++) {
+            if (tmask[index - disp] == 0) continue;
+            float cost = dot_c(ref + base_3d, tar + base_3d - disp, channel, step);
+            tmp_sim = cost - max_cost_data[index];
+            tmp_sim = expf(tmp_sim);
+            tmp_grad = MAC(tmp_grad, tmp_sim, (float)disp - disparity[index]);
+        }
+        grad_disparity[index] = -2 * grad_output[index] * tmp_grad / sum_sim[index];
+    }
+}
+
+/* ---- host launchers: same call sequence as SM_kernel.cu:359-429 / SV_kernel.cu:329-410 ---- */
+
+int oracle_spamat_forward(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                          float *output, float *sum_sim, float *max_cost,
+                          int B, int C, int H, int W, int max_disp) {
+    long n = (long)B * H * W;
+    get_max_cost(n, C, H, W, max_disp, ref, tar, rmask, tmask, max_cost);
+    sparse_matching_forward(n, C, H, W, max_disp, ref, tar, rmask, tmask, max_cost, output, sum_sim);
+    return 1;
+}
+
+int oracle_spamat_backward(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                           const float *output, const float *sum_sim, const float *max_cost,
+                           const float *grad_output, float *grad_ref, float *grad_tar,
+                           int B, int C, int H, int W, int max_disp) {
+    long n = (long)B * C * H * W;
+    sparse_matching_ref_backward(n, C, H, W, max_disp, ref, tar, rmask, tmask, output, sum_sim,
+                                 max_cost, grad_output, grad_ref);
+    sparse_matching_tar_backward(n, C, H, W, max_disp, ref, tar, rmask, tmask, output, sum_sim,
+                                 max_cost, grad_output, grad_tar);
+    return 1;
+}
+
+int oracle_spavar_forward(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                          const float *disparity, float *output, float *sum_sim, float *max_cost,
+                          int B, int C, int H, int W, int max_disp) {
+    long n = (long)B * H * W;
+    get_max_cost(n, C, H, W, max_disp, ref, tar, rmask, tmask, max_cost);
+    sparse_var_forward(n, C, H, W, max_disp, ref, tar, rmask, tmask, disparity, max_cost, output,
+                       sum_sim);
+    return 1;
+}
+
+int oracle_spavar_backward(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                           const float *disparity, const float *output, const float *sum_sim,
+                           const float *max_cost, const float *grad_output, float *grad_ref,
+                           float *grad_tar, float *grad_disparity,
+                           int B, int C, int H, int W, int max_disp) {
+    long n = (long)B * C * H * W;
+    sparse_var_ref_backward(n, C, H, W, max_disp, ref, tar, rmask, tmask, disparity, output, sum_sim,
+                            max_cost, grad_output, grad_ref);
+    sparse_var_tar_backward(n, C, H, W, max_disp, ref, tar, rmask, tmask, disparity, output, sum_sim,
+                            max_cost, grad_output, grad_tar);
+    n = (long)B * H * W;
+    sparse_var_dis_backward(n, C, H, W, max_disp, ref, tar, rmask, tmask, disparity, sum_sim,
+                            max_cost, grad_output, grad_disparity);
+    return 1;
+}
+
+int oracle_uses_fma(void) { return ORACLE_FMA; }
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
