@@ -1,0 +1,266 @@
+#!/usr/bin/env python
+"""bench.py -- DecNet hot-path throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic stereo pairs that are
+already resident in HBM (BASELINE config 2: batch 8, 960x540 -> padded 972x540,
+max_disp 192 -> 216 as the reference rounds it, demo.py:153):
+
+    stage 0   cost volume -> 7x Conv3d(216,216,3^3)+BN+ReLU (+residual) -> Conv3d(216,1)+BN
+              -> soft-argmax                                    [8,216,20,36], D=8
+    stage 1-3 fused SpaMat+SpaVar (masked correlation -> softmax expectation + variance)
+              [8,72,60,108] D=24 / [8,24,180,324] D=72 / [8,8,540,972] D=216
+    N>1       one RCCL all_gather of the per-rank disparity maps (the reference's
+              DataParallel gather, eval.py:146) -- pairs are sharded, weak scaling.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3     # dense fp32 matrix peak (v_mfma_f32_*_f32)
+
+PAD_H, PAD_W, MAX_DISP = 540, 972, 216
+STAGES = [  # (C, H, W, D) for stage 0..3 of the shipped 4-stage / scale-3 network
+    (216, PAD_H // 27, PAD_W // 27, MAX_DISP // 27),
+    (72, PAD_H // 9, PAD_W // 9, MAX_DISP // 9),
+    (24, PAD_H // 3, PAD_W // 3, MAX_DISP // 3),
+    (8, PAD_H, PAD_W, MAX_DISP),
+]
+
+
+def make_inputs(B, dev, density, seed):
+    """Op-level synthetic tensors: features relu(N(0,1)), Bernoulli masks."""
+    feats, masks = [], []
+    for s, (C, H, W, D) in enumerate(STAGES):
+        g = torch.Generator(device=dev).manual_seed(seed + 17 + s)
+        L = torch.relu(torch.randn(B, C, H, W, device=dev, generator=g))
+        R = torch.relu(torch.randn(B, C, H, W, device=dev, generator=g))
+        feats.append((L, R))
+        g = torch.Generator(device=dev).manual_seed(seed + 170 + s)
+        if density >= 1.0:
+            rm = torch.ones(B, H, W, device=dev)
+            tm = torch.ones(B, H, W, device=dev)
+        else:
+            rm = (torch.rand(B, H, W, device=dev, generator=g) < density).float()
+            tm = (torch.rand(B, H, W, device=dev, generator=g) < density).float()
+        masks.append((rm, tm))
+    return feats, masks
+
+
+def make_regularizer(C, dev, seed=17):
+    """Random-init CostRegNetNoDown (conv init as SparseDenseNetRefinementMask.py:248-250)."""
+    import decnet_amd
+    reg = decnet_amd.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func="cor")
+    g = torch.Generator().manual_seed(seed)
+    for u in reg.units():
+        co = u.conv.weight.shape[0]
+        u.conv.weight.data.normal_(0, math.sqrt(2.0 / (27 * co)), generator=g)
+        u.bn.weight.data = torch.rand(co, generator=g) * 0.5 + 0.75
+        u.bn.bias.data = torch.randn(co, generator=g) * 0.1
+        u.bn.running_mean.data = torch.randn(co, generator=g) * 0.1
+        u.bn.running_var.data = torch.rand(co, generator=g) * 0.5 + 0.75
+    return reg.to(dev).eval()
+
+
+class HotPath:
+    def __init__(self, B, dev, density, world):
+        import decnet_amd
+        self.decnet = decnet_amd
+        self.B, self.dev, self.world = B, dev, world
+        self.feats, self.masks = make_inputs(B, dev, density, seed=1000 * (int(os.environ.get("RANK", 0)) + 1))
+        self.reg = make_regularizer(STAGES[0][0], dev)
+        self.stage0 = decnet_amd.Stage0(self.reg)
+        self.outs = [tuple(torch.empty(B, H, W, device=dev) for _ in range(4)) for (_, H, W, _) in STAGES[1:]]
+        self.gathered = torch.empty(world * B, PAD_H, PAD_W, device=dev) if world > 1 else None
+        self.ev = None
+
+    def step(self, events=None):
+        d = self.decnet
+        L, R = self.feats[0]
+        if events is not None:
+            events["s0_beg"].record()
+        pred0 = self.stage0(L, R, STAGES[0][3])
+        if events is not None:
+            events["s0_end"].record()
+        for s in (1, 2, 3):
+            (L, R), (rm, tm) = self.feats[s], self.masks[s]
+            if events is not None and s == 3:
+                events["s3_beg"].record()
+            d.spamatvar_forward(L, R, rm, tm, STAGES[s][3], out=self.outs[s - 1])
+            if events is not None and s == 3:
+                events["s3_end"].record()
+        disp = self.outs[2][0]
+        if self.world > 1:
+            torch.distributed.all_gather_into_tensor(self.gathered, disp)
+        return pred0, disp
+
+
+def time_kernel(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    beg.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return beg.elapsed_time(end) / iters          # ms per call
+
+
+def cpu_baseline(seed=17):
+    """The CPU checker (oracle/: C+OpenMP restatement of the CUDA kernels, torch-CPU stage 0)
+    timed on this box's host cores on ONE pair of the same workload."""
+    import oracle
+    from oracle import stage0 as o0
+    oracle.build()
+    cores = oracle.num_threads()
+    torch.set_num_threads(cores)
+    feats, masks = [], []
+    for s, (C, H, W, D) in enumerate(STAGES):
+        g = torch.Generator().manual_seed(seed + s)
+        feats.append((torch.relu(torch.randn(1, C, H, W, generator=g)),
+                      torch.relu(torch.randn(1, C, H, W, generator=g))))
+        masks.append((torch.ones(1, H, W), torch.ones(1, H, W)))
+    params = o0.random_params(STAGES[0][0], 3)
+    t0 = time.time()
+    with torch.no_grad():
+        o0.stage0_forward(feats[0][0], feats[0][1], params, STAGES[0][3])
+    t_s0 = time.time() - t0
+    t0 = time.time()
+    for s in (1, 2, 3):
+        (L, R), (rm, tm) = feats[s], masks[s]
+        o, _, _ = oracle.spamat_forward(L, R, rm, tm, STAGES[s][3])
+        oracle.spavar_forward(L, R, rm, tm, o, STAGES[s][3])
+    t_sp = time.time() - t0
+    total = t_s0 + t_sp
+    return {"value": 1.0 / total, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "1 pair 972x540 max_disp 216, mask density 1.0: torch-CPU stage 0 %.2f s + "
+                      "C/OpenMP SpaMat+SpaVar stages 1-3 %.2f s" % (t_s0, t_sp)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-gpu", type=int, default=8)
+    ap.add_argument("--mask-density", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    B = args.pairs_per_gpu
+    hp = HotPath(B, dev, args.mask_density, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            hp.step()
+        ev = [{k: torch.cuda.Event(enable_timing=True) for k in ("s0_beg", "s0_end", "s3_beg", "s3_end")}
+              for _ in range(args.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            hp.step(ev[i])
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        pairs = world * B * args.steps
+        # --- dominant kernel: conv3d_k3_igemm (7 launches inside stage 0), live events -------
+        C0, H0, W0, D0 = STAGES[0]
+        M = B * D0 * H0 * W0
+        conv_flop = 2.0 * 27 * C0 * C0 * M
+        s0_ms = sum(e["s0_beg"].elapsed_time(e["s0_end"]) for e in ev) / args.steps
+        with torch.no_grad():
+            cv = hp.stage0._cv[next(iter(hp.stage0._cv))]
+            P = hp.reg.prepare()
+            from decnet_amd import _lib
+            L = _lib.lib()
+            a, b, _ = hp.reg._workspace(dev, cv.numel())
+            st = torch.cuda.current_stream().cuda_stream
+
+            def one_conv():
+                p = P[0]
+                L.decnet_conv3d_bn_act(cv.data_ptr(), p["w"].data_ptr(), p["scale"].data_ptr(),
+                                       p["shift"].data_ptr(), None, a.data_ptr(), B, D0, H0, W0, C0, C0, 1, st)
+            conv_ms = time_kernel(one_conv, 10)
+            # --- cost-volume pass (fused SpaMat+SpaVar, stage 3), live events + both densities
+            C3, H3, W3, D3 = STAGES[3]
+            s3_bytes = 4.0 * B * H3 * W3 * (2 * C3 + 2 + 4)
+            s3_ms = sum(e["s3_beg"].elapsed_time(e["s3_end"]) for e in ev) / args.steps
+            sparse = None
+            if args.mask_density >= 1.0:
+                _, m2 = make_inputs(B, dev, 0.1, seed=4242)
+                (Lf, Rf) = hp.feats[3]
+                s3s_ms = time_kernel(lambda: hp.decnet.spamatvar_forward(Lf, Rf, m2[3][0], m2[3][1], D3,
+                                                                         out=hp.outs[2]), 10)
+                sparse = {"bound": "hbm", "achieved": s3_bytes / s3s_ms / 1e6, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": s3_bytes / s3s_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                          "kernel": "spamat fused fwd, stage 3", "mask_density": 0.1, "ms": s3s_ms}
+        out = {
+            "metric": "stereo pairs/sec at 960x540x192disp (hot path: stage-0 dense + SpaMat/SpaVar stages 1-3)",
+            "value": pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: batch=%d synthetic 960x540 pairs per GPU (padded "
+                                   "972x540), max_disp 192->216, feature maps of the 4-stage/scale-3 net, "
+                                   "random-init CostRegNetNoDown(216)" % B,
+                       "pairs_per_gpu": B, "mask_density": args.mask_density,
+                       "parallelism": "dp%d (pairs sharded, all_gather of disparity maps)" % world},
+            "roofline": {"bound": "mfma", "achieved": conv_flop / conv_ms / 1e9, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": conv_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
+                         "traffic": None, "kernel": "conv3d_k3_igemm (216->216, 3^3, M=%d)" % M,
+                         "ms": conv_ms, "flop_per_launch": conv_flop, "stage0_ms_in_step": s0_ms},
+            "roofline_costvol": {"bound": "hbm", "achieved": s3_bytes / s3_ms / 1e6, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": s3_bytes / s3_ms / 1e6 / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "spamat fused fwd, stage 3",
+                                 "mask_density": args.mask_density, "ms": s3_ms,
+                                 "bytes_per_launch": s3_bytes},
+        }
+        if sparse:
+            out["roofline_costvol_sparse"] = sparse
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

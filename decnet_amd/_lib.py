@@ -1,0 +1,68 @@
+"""ctypes binding of libdecnet_hip.so (the C ABI declared in include/decnet_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes  (kept in the order of include/decnet_hip.h; tests check every symbol)
+SIGNATURES = {
+    "decnet_spamat_forward": [_P] * 7 + [_I] * 5 + [_P],
+    "decnet_spamat_backward": [_P] * 10 + [_I] * 5 + [_P],
+    "decnet_spavar_forward": [_P] * 8 + [_I] * 5 + [_P],
+    "decnet_spavar_backward": [_P] * 12 + [_I] * 5 + [_P],
+    "decnet_spamatvar_forward": [_P] * 8 + [_I] * 5 + [_P],
+    "decnet_costvol_forward": [_P] * 3 + [_I] * 5 + [_P],
+    "decnet_conv3d_packed_cout": [_I],
+    "decnet_conv3d_pack_weight": [_P, _P, _I, _I, _P],
+    "decnet_conv3d_bn_act": [_P] * 6 + [_I] * 7 + [_P],
+    "decnet_conv3d_cout1_softargmax": [_P, _P, _F, _F, _P, _P] + [_I] * 5 + [_P],
+    "decnet_disparity_regression": [_P] * 3 + [_I] * 4 + [_P],
+    "decnet_ncdhw_to_ndhwc": [_P, _P] + [_I] * 5 + [_P],
+    "decnet_ndhwc_to_ncdhw": [_P, _P] + [_I] * 5 + [_P],
+}
+
+ERRORS = {-1: "null pointer", -2: "bad shape", -3: "shape not supported by the gfx950 kernels"}
+
+_lib = None
+
+
+class DecnetHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DecnetHipError(
+                "%s not found: build it with `python -m decnet_amd.build` (hipcc, gfx950). "
+                "decnet_amd has no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = _I
+        h.decnet_version.restype = ctypes.c_char_p
+        h.decnet_version.argtypes = []
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise DecnetHipError("%s: %s (code %d)" % (what, ERRORS.get(rc, "error"), rc))
+    raise DecnetHipError("%s: HIP launch failed, hipError_t=%d" % (what, rc))
+
+
+def version():
+    return lib().decnet_version().decode()

@@ -1,0 +1,85 @@
+// decnet_amd/csrc/capi.hip -- extern "C" entry points for SpaMat / SpaVar (include/decnet_hip.h).
+#include "common.h"
+
+// kernels in spamat_rowtile.hip
+int decnet_rowtile_forward(int mode, const float *ref, const float *tar, const float *rmask,
+                           const float *tmask, const float *disparity, float *out, float *var_out,
+                           float *sum_sim, float *max_cost, int B, int C, int H, int W, int max_disp,
+                           hipStream_t stream);
+int decnet_rowtile_backward(int var, const float *ref, const float *tar, const float *rmask,
+                            const float *tmask, const float *disparity, const float *out,
+                            const float *sum_sim, const float *max_cost, const float *grad_out,
+                            float *grad_ref, float *grad_tar, float *grad_disp, int B, int C, int H,
+                            int W, int max_disp, hipStream_t stream);
+int decnet_check_spamat_args(const void *const *ptrs, int n, int B, int C, int H, int W,
+                             int max_disp);
+
+extern "C" {
+
+const char *decnet_version(void) { return "decnet_hip 0.1.0 gfx950"; }
+
+int decnet_spamat_forward(const float *ref, const float *tar, const float *ref_mask,
+                          const float *tar_mask, float *output, float *sum_similarities,
+                          float *max_cost, int B, int C, int H, int W, int max_disp, void *stream) {
+    const void *p[] = {ref, tar, ref_mask, tar_mask, output, sum_similarities, max_cost};
+    int rc = decnet_check_spamat_args(p, 7, B, C, H, W, max_disp);
+    if (rc) return rc;
+    return decnet_rowtile_forward(0, ref, tar, ref_mask, tar_mask, nullptr, output, nullptr,
+                                  sum_similarities, max_cost, B, C, H, W, max_disp,
+                                  (hipStream_t)stream);
+}
+
+int decnet_spavar_forward(const float *ref, const float *tar, const float *ref_mask,
+                          const float *tar_mask, const float *disparity, float *output,
+                          float *sum_similarities, float *max_cost, int B, int C, int H, int W,
+                          int max_disp, void *stream) {
+    const void *p[] = {ref, tar, ref_mask, tar_mask, disparity, output, sum_similarities, max_cost};
+    int rc = decnet_check_spamat_args(p, 8, B, C, H, W, max_disp);
+    if (rc) return rc;
+    return decnet_rowtile_forward(1, ref, tar, ref_mask, tar_mask, disparity, nullptr, output,
+                                  sum_similarities, max_cost, B, C, H, W, max_disp,
+                                  (hipStream_t)stream);
+}
+
+int decnet_spamatvar_forward(const float *ref, const float *tar, const float *ref_mask,
+                             const float *tar_mask, float *output, float *variance,
+                             float *sum_similarities, float *max_cost, int B, int C, int H, int W,
+                             int max_disp, void *stream) {
+    const void *p[] = {ref, tar, ref_mask, tar_mask, output, variance, sum_similarities, max_cost};
+    int rc = decnet_check_spamat_args(p, 8, B, C, H, W, max_disp);
+    if (rc) return rc;
+    return decnet_rowtile_forward(2, ref, tar, ref_mask, tar_mask, nullptr, output, variance,
+                                  sum_similarities, max_cost, B, C, H, W, max_disp,
+                                  (hipStream_t)stream);
+}
+
+int decnet_spamat_backward(const float *ref, const float *tar, const float *ref_mask,
+                           const float *tar_mask, const float *output,
+                           const float *sum_similarities, const float *max_cost,
+                           const float *grad_output, float *grad_ref, float *grad_tar, int B, int C,
+                           int H, int W, int max_disp, void *stream) {
+    const void *p[] = {ref, tar, ref_mask, tar_mask, output, sum_similarities, max_cost,
+                       grad_output, grad_ref, grad_tar};
+    int rc = decnet_check_spamat_args(p, 10, B, C, H, W, max_disp);
+    if (rc) return rc;
+    return decnet_rowtile_backward(0, ref, tar, ref_mask, tar_mask, nullptr, output,
+                                   sum_similarities, max_cost, grad_output, grad_ref, grad_tar,
+                                   nullptr, B, C, H, W, max_disp, (hipStream_t)stream);
+}
+
+int decnet_spavar_backward(const float *ref, const float *tar, const float *ref_mask,
+                           const float *tar_mask, const float *disparity, const float *output,
+                           const float *sum_similarities, const float *max_cost,
+                           const float *grad_output, float *grad_ref, float *grad_tar,
+                           float *grad_disparity, int B, int C, int H, int W, int max_disp,
+                           void *stream) {
+    const void *p[] = {ref, tar, ref_mask, tar_mask, disparity, output, sum_similarities, max_cost,
+                       grad_output, grad_ref, grad_tar, grad_disparity};
+    int rc = decnet_check_spamat_args(p, 12, B, C, H, W, max_disp);
+    if (rc) return rc;
+    return decnet_rowtile_backward(1, ref, tar, ref_mask, tar_mask, disparity, output,
+                                   sum_similarities, max_cost, grad_output, grad_ref, grad_tar,
+                                   grad_disparity, B, C, H, W, max_disp, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,441 @@
+// decnet_amd/csrc/stage0.hip -- stage-0 dense path on gfx950: cost volume -> Conv3d
+// aggregation (f32 MFMA implicit GEMM) -> soft-argmax.
+//
+// Reference (modules/submodule.py): get_disp_samples :389-390, GetCostVolume :479-522,
+// Conv3dUnit :115-123, CostRegNetNoDown :650-662, disparity_regression :766-777.
+// The reference materialises [B,C,D,H,W] volumes in NCDHW and runs 8 cuDNN Conv3d +
+// 8 BatchNorm + 7 ReLU + softmax/mul/sum kernels.  Here activations are channels-last
+// [B,D,H,W,C] so that the implicit-GEMM K dimension (27 taps x Ci) is contiguous, BN and
+// ReLU (and the residual add) are the GEMM epilogue, and the 216->1 layer is fused with
+// the softmax regression.
+//
+// Conv3d as implicit GEMM:  Y[M, Co] = sum_{tap, ci} X[shift_tap(m), ci] * Wp[tap, ci, co],
+// M = B*D*H*W output positions.  fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 fma chain, no reduced precision anywhere).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CONV_BN = 224;   // Co tile, 14 MFMA columns-of-16 (216 -> 224, 3.6 % padding)
+constexpr int CONV_BK = 24;    // 216 = 9 * 24
+constexpr int A_PITCH = 26;    // == 2 (mod 4): the 32 lanes (row i, k-quad kq<2) hit 32 banks
+constexpr int B_PITCH = 240;   // == 16 (mod 32): rows kq, kq+1 land on opposite bank halves
+constexpr int CONV_THREADS = 256;
+
+// ----------------------------------- cost volume ---------------------------------------
+// cost[b,d,y,x,c] = (x >= d ? L[b,c,y,x] : 0) * bilinear(R[b,c]; ix, iy), zero padding.
+// Coordinates are formed with the same fp32 operation sequence as the reference + torch:
+//   cx = (x-d) / ((W-1)/2) - 1      (submodule.py:497-498)
+//   ix = ((cx + 1) * W - 1) / 2     (grid_sample, align_corners=False)
+__global__ void costvol_cor_ndhwc(const float *__restrict__ left, const float *__restrict__ right,
+                                  float *__restrict__ cost, int B, int C, int H, int W, int D,
+                                  size_t total) {
+#pragma clang fp contract(off)
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int c = (int)(idx % C);
+    size_t p = idx / C;
+    int x = (int)(p % W); p /= W;
+    int y = (int)(p % H); p /= H;
+    int d = (int)(p % D);
+    int b = (int)(p / D);
+    const size_t plane = (size_t)H * W;
+    const float *Lp = left + ((size_t)b * C + c) * plane;
+    const float *Rp = right + ((size_t)b * C + c) * plane;
+    float l = x >= d ? Lp[(size_t)y * W + x] : 0.f;          // submodule.py:506-508
+    float cx = (float)(x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
+    float cy = (float)y / ((float)(H - 1.0) / 2.0f) - 1.0f;
+    float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f;
+    float iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    float fx = floorf(ix), fy = floorf(iy);
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    float wx1 = ix - fx, wx0 = 1.0f - wx1, wy1 = iy - fy, wy0 = 1.0f - wy1;
+    bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    float r = 0.f;
+    if (vy0 && vx0) r += Rp[(size_t)y0 * W + x0] * (wx0 * wy0);
+    if (vy0 && vx1) r += Rp[(size_t)y0 * W + x1] * (wx1 * wy0);
+    if (vy1 && vx0) r += Rp[(size_t)y1 * W + x0] * (wx0 * wy1);
+    if (vy1 && vx1) r += Rp[(size_t)y1 * W + x1] * (wx1 * wy1);
+    cost[idx] = l * r;                                       // submodule.py:521
+}
+
+// ----------------------------------- weight repack -------------------------------------
+// torch [Co][Ci][27] -> [27][Ci][CoP], zero padded in co.
+__global__ void pack_weight(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci,
+                            int CoP, size_t total) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int co = (int)(idx % CoP);
+    size_t p = idx / CoP;
+    int ci = (int)(p % Ci);
+    int tap = (int)(p / Ci);
+    wp[idx] = co < Co ? w[((size_t)co * Ci + ci) * 27 + tap] : 0.f;
+}
+
+// ------------------------------ Conv3d k3 s1 p1 implicit GEMM --------------------------
+// Workgroup: 256 threads = 4 waves as 2 (M) x 2 (N); tile BM x 224; wave tile (BM/2) x 112
+// = TM x 7 MFMA tiles of 16x16.  K loop: 27 taps x ceil(Ci/24) chunks, LDS double
+// buffered, next chunk prefetched global->registers while the current one is on the MFMAs.
+// LDS: As[2][BM][26] (k contiguous, as in HBM) | Bs[2][24][240] (co contiguous).
+template <int BM>
+__global__ __launch_bounds__(CONV_THREADS) void conv3d_k3_igemm(
+    const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ y,
+    int D, int H, int W, int Ci, int Co, int relu, int M) {
+    constexpr int TM = BM / 32, TN = 7;
+    constexpr int A_F4 = BM * (CONV_BK / 4);
+    constexpr int A_PER_T = (A_F4 + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int B_F4 = CONV_BK * (CONV_BN / 4);
+    constexpr int B_PER_T = (B_F4 + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int A_TILE = BM * A_PITCH, B_TILE = CONV_BK * B_PITCH;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                 // 2 * A_TILE
+    float *Bs = smem + 2 * A_TILE;    // 2 * B_TILE
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int m_block = blockIdx.x * BM;
+
+    // rows of the A tile this thread stages (same rows every K step)
+    int a_lds[A_PER_T];     // LDS offset (floats) or -1
+    int a_pos[A_PER_T];     // linear position index ((b*D+d)*H+y)*W+x
+    int a_dyx[A_PER_T];     // d<<20 | y<<10 | x
+    int a_q4[A_PER_T];      // 4*q: channel offset inside the chunk
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+        int idx = tid + i * CONV_THREADS;
+        int ml = idx / (CONV_BK / 4), q = idx - ml * (CONV_BK / 4);
+        int m = m_block + ml;
+        bool ok = idx < A_F4 && m < M;
+        a_lds[i] = idx < A_F4 ? ml * A_PITCH + 4 * q : -1;
+        a_q4[i] = 4 * q;
+        int mm = ok ? m : 0;
+        int xx = mm % W; int t = mm / W;
+        int yy = t % H; t /= H;
+        int dd = t % D;
+        a_pos[i] = mm;
+        a_dyx[i] = ok ? ((dd << 20) | (yy << 10) | xx) : -1;
+    }
+    int b_lds[B_PER_T], b_k[B_PER_T], b_q4[B_PER_T];
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+        int idx = tid + i * CONV_THREADS;
+        int kk = idx / (CONV_BN / 4), q = idx - kk * (CONV_BN / 4);
+        b_lds[i] = idx < B_F4 ? kk * B_PITCH + 4 * q : -1;
+        b_k[i] = kk;
+        b_q4[i] = 4 * q;
+    }
+
+    const int nchunk = (Ci + CONV_BK - 1) / CONV_BK;
+    const int nstep = 27 * nchunk;
+
+    float4 ra[A_PER_T], rb[B_PER_T];
+    auto prefetch = [&](int s) {
+        int tap = s / nchunk, ci0 = (s - tap * nchunk) * CONV_BK;
+        int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
+        int tap_off = (kd * H + kh) * W + kw;
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int dyx = a_dyx[i];
+            if (dyx >= 0) {
+                int dd = (dyx >> 20) + kd, yy = ((dyx >> 10) & 1023) + kh, xx = (dyx & 1023) + kw;
+                int ci = ci0 + a_q4[i];
+                if ((unsigned)dd < (unsigned)D && (unsigned)yy < (unsigned)H &&
+                    (unsigned)xx < (unsigned)W && ci < Ci)
+                    v = *reinterpret_cast<const float4 *>(x + (size_t)(a_pos[i] + tap_off) * Ci + ci);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int ci = ci0 + b_k[i];
+            if (b_lds[i] >= 0 && ci < Ci)
+                v = *reinterpret_cast<const float4 *>(wp + ((size_t)tap * Ci + ci) * CONV_BN + b_q4[i]);
+            rb[i] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+        float *a = As + buf * A_TILE, *b = Bs + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i)
+            if (a_lds[i] >= 0) {      // rows are 8-byte aligned (pitch 26), not 16
+                *reinterpret_cast<float2 *>(a + a_lds[i]) = make_float2(ra[i].x, ra[i].y);
+                *reinterpret_cast<float2 *>(a + a_lds[i] + 2) = make_float2(ra[i].z, ra[i].w);
+            }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<float4 *>(b + b_lds[i]) = rb[i];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    prefetch(0);
+    stage(0);
+    __syncthreads();
+    const int a_row0 = (wm * (BM / 2) + i16) * A_PITCH + kq;
+    const int b_col0 = kq * B_PITCH + wn * (CONV_BN / 2) + i16;
+    for (int s = 0; s < nstep; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstep) prefetch(s + 1);
+        const float *a = As + buf * A_TILE + a_row0;
+        const float *b = Bs + buf * B_TILE + b_col0;
+#pragma unroll
+        for (int kk = 0; kk < CONV_BK / 4; ++kk) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * A_PITCH + kk * 4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = b[kk * 4 * B_PITCH + j * 16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nstep) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: BN (folded scale/shift) -> ReLU -> + residual.  C/D layout of 16x16x4:
+    // col = lane & 15, row = 4 * (lane >> 4) + r.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int co = wn * (CONV_BN / 2) + j * 16 + i16;
+        if (co >= Co) continue;
+        float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = m_block + wm * (BM / 2) + i * 16 + kq * 4 + r;
+                if (m >= M) continue;
+                float v = fmaf(acc[i][j][r], sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+                size_t o = (size_t)m * Co + co;
+                if (residual) v += residual[o];
+                y[o] = v;
+            }
+    }
+}
+
+// --------------------- last layer (Ci -> 1) + BN + softmax regression -------------------
+// One wave per pixel (b,y,x); lanes stride the channel axis with float4 loads; the D
+// regularised costs never leave registers before the soft-argmax.
+__global__ __launch_bounds__(256) void conv3d_cout1_softargmax(
+    const float *__restrict__ x, const float *__restrict__ w, float scale, float shift,
+    float *__restrict__ reg, float *__restrict__ pred, int B, int D, int H, int W, int Ci) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];      // [27][Ci]
+    for (int i = threadIdx.x; i < 27 * Ci; i += blockDim.x) {
+        int tap = i / Ci, ci = i - tap * Ci;
+        ws[i] = w[(size_t)ci * 27 + tap];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npix = B * H * W;
+    for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
+        int xx = pix % W, t = pix / W;
+        int yy = t % H, b = t / H;
+        float m = -INFINITY, S = 0.f, T = 0.f;
+        for (int d = 0; d < D; ++d) {
+            float acc = 0.f;
+            for (int tap = 0; tap < 27; ++tap) {
+                int zd = d + tap / 9 - 1, zy = yy + (tap / 3) % 3 - 1, zx = xx + tap % 3 - 1;
+                if ((unsigned)zd >= (unsigned)D || (unsigned)zy >= (unsigned)H ||
+                    (unsigned)zx >= (unsigned)W)
+                    continue;                                        // wave-uniform
+                const float *row = x + ((((size_t)b * D + zd) * H + zy) * W + zx) * Ci;
+                const float *wr = ws + tap * Ci;
+                for (int c = lane * 4; c < Ci; c += 256) {
+                    float4 xv = *reinterpret_cast<const float4 *>(row + c);
+                    float4 wv = *reinterpret_cast<const float4 *>(wr + c);
+                    acc = fmaf(xv.x, wv.x, acc);
+                    acc = fmaf(xv.y, wv.y, acc);
+                    acc = fmaf(xv.z, wv.z, acc);
+                    acc = fmaf(xv.w, wv.w, acc);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            float cost = fmaf(acc, scale, shift);
+            if (reg && lane == 0) reg[(((size_t)b * D + d) * H + yy) * W + xx] = cost;
+            float mn = fmaxf(m, cost);
+            float r = expf(m - mn), e = expf(cost - mn);             // m = -inf -> r = 0
+            S = fmaf(S, r, e);
+            T = fmaf(T, r, e * (float)d);
+            m = mn;
+        }
+        if (lane == 0) pred[pix] = T / S;
+    }
+}
+
+// disparity_regression for arbitrary samples: thread per pixel, coalesced over x.
+__global__ void disparity_regression_kernel(const float *__restrict__ cost,
+                                            const float *__restrict__ samples,
+                                            float *__restrict__ pred, int B, int S, int HW) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    int b = idx / HW, p = idx - b * HW;
+    const float *c = cost + (size_t)b * S * HW + p;
+    const float *d = samples + (size_t)b * S * HW + p;
+    float m = -INFINITY;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, c[(size_t)s * HW]);
+    float sum = 0.f, acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+        float e = expf(c[(size_t)s * HW] - m);
+        sum += e;
+        acc = fmaf(e, d[(size_t)s * HW], acc);
+    }
+    pred[idx] = acc / sum;
+}
+
+// [B][R][Cn] <-> [B][Cn][R] tiled transpose (32x32 through LDS, both sides coalesced).
+__global__ void transpose_inner(const float *__restrict__ src, float *__restrict__ dst, int R,
+                                int Cn) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * R * Cn;
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < R && c < Cn) tile[i][threadIdx.x] = src[base + (size_t)r * Cn + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < Cn) dst[base + (size_t)c * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+template <int BM>
+int launch_conv(const float *x, const float *wp, const float *scale, const float *shift,
+                const float *residual, float *y, int D, int H, int W, int Ci, int Co, int relu,
+                int M, hipStream_t stream) {
+    size_t lds = 4 * (size_t)(2 * BM * A_PITCH + 2 * CONV_BK * B_PITCH);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv3d_k3_igemm<BM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(conv3d_k3_igemm<BM>, dim3(ceil_div(M, BM)), dim3(CONV_THREADS), lds, stream,
+                       x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M);
+    return decnet_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int decnet_costvol_forward(const float *left, const float *right, float *cost, int B, int C, int H,
+                           int W, int D, void *stream) {
+    if (!left || !right || !cost) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || C < 1 || H < 2 || W < 2 || D < 1) return DECNET_ERR_BAD_SHAPE;
+    size_t total = (size_t)B * D * H * W * C;
+    if (total >= ((size_t)1 << 40)) return DECNET_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, left, right, cost, B, C, H, W, D, total);
+    return decnet_launch_status();
+}
+
+int decnet_conv3d_packed_cout(int Co) { return Co >= 1 && Co <= CONV_BN ? CONV_BN : -1; }
+
+int decnet_conv3d_pack_weight(const float *w, float *wp, int Co, int Ci, void *stream) {
+    if (!w || !wp) return DECNET_ERR_NULL_POINTER;
+    if (Co < 1 || Ci < 1) return DECNET_ERR_BAD_SHAPE;
+    if (Co > CONV_BN) return DECNET_ERR_UNSUPPORTED;
+    size_t total = (size_t)27 * Ci * CONV_BN;
+    hipLaunchKernelGGL(pack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, wp, Co, Ci, CONV_BN, total);
+    return decnet_launch_status();
+}
+
+int decnet_conv3d_bn_act(const float *x, const float *wp, const float *scale, const float *shift,
+                         const float *residual, float *y, int B, int D, int H, int W, int Ci,
+                         int Co, int relu, void *stream) {
+    if (!x || !wp || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1) return DECNET_ERR_BAD_SHAPE;
+    if (D > 1023 || H > 1023 || W > 1023) return DECNET_ERR_UNSUPPORTED;
+    if (Ci % 4 != 0 || Co > CONV_BN) return DECNET_ERR_UNSUPPORTED;
+    double Md = (double)B * D * H * W;
+    if (Md * (Ci > Co ? Ci : Co) >= 2147483648.0 * 4) return DECNET_ERR_BAD_SHAPE;
+    if (Md >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
+    int M = (int)Md;
+    // tile height: fewest rounds over 256 CUs, ties -> taller tile (more weight reuse)
+    const int cands[4] = {192, 128, 96, 64};
+    int best = 192;
+    long best_cost = -1;
+    for (int i = 0; i < 4; ++i) {
+        long blocks = ceil_div(M, cands[i]);
+        long cost = ((blocks + 255) / 256) * cands[i];
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cands[i]; }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (best) {
+        case 192: return launch_conv<192>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+        case 128: return launch_conv<128>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+        case 96: return launch_conv<96>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+        default: return launch_conv<64>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+    }
+}
+
+int decnet_conv3d_cout1_softargmax(const float *x, const float *w, float scale, float shift,
+                                   float *reg, float *pred, int B, int D, int H, int W, int Ci,
+                                   void *stream) {
+    if (!x || !w || !pred) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || Ci < 1) return DECNET_ERR_BAD_SHAPE;
+    if (Ci % 4 != 0) return DECNET_ERR_UNSUPPORTED;
+    size_t lds = (size_t)27 * Ci * 4;
+    if (lds > DECNET_LDS_BUDGET) return DECNET_ERR_UNSUPPORTED;
+    double npix = (double)B * H * W;
+    if (npix * D >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
+    int blocks = (int)((npix + 3) / 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(conv3d_cout1_softargmax, dim3(blocks), dim3(256), lds, (hipStream_t)stream,
+                       x, w, scale, shift, reg, pred, B, D, H, W, Ci);
+    return decnet_launch_status();
+}
+
+int decnet_disparity_regression(const float *cost, const float *samples, float *pred, int B, int S,
+                                int H, int W, void *stream) {
+    if (!cost || !samples || !pred) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || S < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
+    if ((double)B * S * H * W >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
+    int n = B * H * W;
+    hipLaunchKernelGGL(disparity_regression_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, cost, samples, pred, B, S, H * W);
+    return decnet_launch_status();
+}
+
+static int transpose(const float *src, float *dst, int B, int R, int Cn, void *stream) {
+    if (!src || !dst) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || R < 1 || Cn < 1 || B > 65535) return DECNET_ERR_BAD_SHAPE;
+    if (ceil_div(R, 32) > 65535) return DECNET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(transpose_inner, dim3(ceil_div(Cn, 32), ceil_div(R, 32), B), dim3(32, 8), 0,
+                       (hipStream_t)stream, src, dst, R, Cn);
+    return decnet_launch_status();
+}
+
+int decnet_ncdhw_to_ndhwc(const float *src, float *dst, int B, int C, int D, int H, int W,
+                          void *stream) {
+    if (C < 1 || D < 1 || H < 1 || W < 1 || (double)D * H * W >= 2147483648.0)
+        return DECNET_ERR_BAD_SHAPE;
+    return transpose(src, dst, B, C, D * H * W, stream);       // [B][C][S] -> [B][S][C]
+}
+
+int decnet_ndhwc_to_ncdhw(const float *src, float *dst, int B, int C, int D, int H, int W,
+                          void *stream) {
+    if (C < 1 || D < 1 || H < 1 || W < 1 || (double)D * H * W >= 2147483648.0)
+        return DECNET_ERR_BAD_SHAPE;
+    return transpose(src, dst, B, D * H * W, C, stream);       // [B][S][C] -> [B][C][S]
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+"""Stage-0 dense path (coarsest level) behind the reference's own names.
+
+Reference (modules/submodule.py): get_disp_samples :376-424, GetCostVolume :428-562,
+Conv3dUnit :90-123, CostRegNetNoDown :608-662, disparity_regression :766-777; used by
+SparseDenseNetRefinementMask.forward :127-137.
+
+The classes keep the reference's constructor arguments, attribute names and state_dict
+keys (``conv0.0.conv.weight``, ``conv0.0.bn.running_mean`` ...) so a checkpoint of the
+reference loads unchanged.  Activations between the HIP kernels are channels-last
+[B,D,H,W,C]; tensors handed back to callers have the reference's logical shapes
+([B,C,D,H,W] cost volume is returned as a permuted view of the channels-last buffer).
+
+Inference (eval mode, no autograd) only: the reference's training path through these
+modules is not runnable as shipped and is outside the hot-path scope.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import _chk, _stream
+
+BN_EPS = 1e-5
+
+
+def get_disp_samples(max_dis, feature_map, stage_id=0, disprity_map=None, step=1, samp_num=9,
+                     sample_spa_size=None):
+    """submodule.py:376-424, stage-0 branch (:389-390): arange(max_dis) broadcast to
+    [B,max_dis,H,W] (an expanded view, nothing is materialised)."""
+    if not (disprity_map is None or step == -1 or stage_id == 0):
+        raise NotImplementedError(
+            "only the stage-0 sampling (arange) is on the hot path; the neighbourhood sampler "
+            "(submodule.py:391-411) is never reached by SparseDenseNetRefinementMask")
+    B, _, H, W = feature_map.size()
+    return torch.arange(int(max_dis), dtype=feature_map.dtype,
+                        device=feature_map.device).expand(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def _ndhwc_view(x):
+    """If x ([B,C,D,H,W]) is a permuted view of a contiguous [B,D,H,W,C] buffer return that
+    buffer, else None."""
+    y = x.permute(0, 2, 3, 4, 1)
+    return y if y.is_contiguous() else None
+
+
+def _to_ndhwc(x):
+    y = _ndhwc_view(x)
+    if y is not None:
+        return y
+    x = x.contiguous()
+    B, C, D, H, W = x.shape
+    out = torch.empty((B, D, H, W, C), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().decnet_ncdhw_to_ndhwc(x.data_ptr(), out.data_ptr(), B, C, D, H, W, _stream(x))
+    _lib.check(rc, "decnet_ncdhw_to_ndhwc")
+    return out
+
+
+def costvol_ndhwc(left, right, max_disp, out=None):
+    """[B,C,H,W] x2 -> channels-last cost volume [B,D,H,W,C] (cost_func="cor")."""
+    _chk("left_feature_map", left)
+    B, C, H, W = left.shape
+    _chk("right_feature_map", right, (B, C, H, W))
+    D = int(max_disp)
+    if out is None:
+        out = torch.empty((B, D, H, W, C), dtype=torch.float32, device=left.device)
+    with torch.cuda.device(left.device):
+        rc = _lib.lib().decnet_costvol_forward(left.data_ptr(), right.data_ptr(), out.data_ptr(),
+                                               B, C, H, W, D, _stream(left))
+    _lib.check(rc, "decnet_costvol_forward")
+    return out
+
+
+class GetCostVolume(nn.Module):
+    """forward: compute the cost volume with warped features  (submodule.py:428-562)
+
+    Only the configuration the shipped network uses is implemented on the GPU:
+    warp_ope="homgrp", cost_func="cor", disp_samples = get_disp_samples(stage 0).
+    return: cost volume, N*C*S*H*W (a view of the channels-last buffer)."""
+
+    def __init__(self, warp_ope="homgrp", cost_func="ssd"):
+        super(GetCostVolume, self).__init__()
+        assert cost_func in ["ssd", "cor", "cat"], "no such cost_func: {}".format(cost_func)
+        self.warp_ope = warp_ope
+        self.cost_func = cost_func
+
+    def forward(self, left_feature_map, right_feature_map, **kargs):
+        if self.warp_ope != "homgrp" or self.cost_func != "cor":
+            raise NotImplementedError("the gfx950 path implements warp_ope='homgrp', "
+                                      "cost_func='cor' (demo.sh / eval.sh)")
+        if "disp_samples" in kargs and kargs["disp_samples"] is not None:
+            D = int(kargs["disp_samples"].size(1))      # must be the stage-0 arange samples
+        else:
+            D = int(kargs["max_disp"])
+        cv = costvol_ndhwc(left_feature_map.contiguous(), right_feature_map.contiguous(), D)
+        return cv.permute(0, 4, 1, 2, 3)
+
+
+class Conv3dUnit(nn.Module):
+    """Parameter container with the reference's layout (submodule.py:90-123): .conv
+    (Conv3d k3 s1 p1, no bias) and .bn (BatchNorm3d); executed by CostRegNetNoDown."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True,
+                 bn_momentum=0.1, **kwargs):
+        super(Conv3dUnit, self).__init__()
+        assert kernel_size == 3 and stride == 1 and bn and kwargs.get("padding", 1) == 1
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=False,
+                              padding=1)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum)
+        self.relu = relu
+
+
+class CostRegNetNoDown(nn.Module):
+    """forward: regularise the cost volume  (submodule.py:608-662)
+    args:    x: cost volume, N*C*S*H*W
+    return:  regularised cost volume, N*S*H*W"""
+
+    def __init__(self, in_channels, base_channels, cost_func, down_scale=3):
+        super(CostRegNetNoDown, self).__init__()
+        if cost_func == "cat":
+            raise NotImplementedError("cost_func='cat' (conv_pre) is not used by the shipped net")
+        self.cost_func = cost_func
+        C = in_channels
+        self.conv0 = nn.Sequential(Conv3dUnit(C, C, padding=1), Conv3dUnit(C, C, padding=1))
+        self.conv1 = nn.Sequential(Conv3dUnit(C, C, padding=1), Conv3dUnit(C, C, padding=1),
+                                   Conv3dUnit(C, C, padding=1))
+        self.conv2 = nn.Sequential(Conv3dUnit(C, C, padding=1), Conv3dUnit(C, C, padding=1),
+                                   Conv3dUnit(C, 1, padding=1, relu=False))
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+
+    def units(self):
+        return list(self.conv0) + list(self.conv1) + list(self.conv2)
+
+    # ---- parameter preparation (once per weight version): repack + BN folding -----------
+    def _key(self):
+        k = []
+        for u in self.units():
+            for t in (u.conv.weight, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var):
+                k.append((t.data_ptr(), t._version))
+        return tuple(k)
+
+    def prepare(self):
+        """Repack the 7 wide Conv3d weights to [27,Ci,CoP] on the device and fold eval-mode
+        BatchNorm into per-channel scale/shift.  Cached until a parameter changes."""
+        key = self._key()
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        units = self.units()
+        dev = units[0].conv.weight.device
+        if dev.type != "cuda":
+            raise _lib.DecnetHipError("CostRegNetNoDown parameters are on %s: move the module to "
+                                      "the MI355X (no CPU fallback)" % dev)
+        L = _lib.lib()
+        packed = []
+        with torch.no_grad(), torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for i, u in enumerate(units):
+                w = u.conv.weight.detach().float().contiguous()
+                Co, Ci = int(w.shape[0]), int(w.shape[1])
+                bn = u.bn
+                eps = float(bn.eps)
+                scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + eps))
+                shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+                if i < 7:
+                    CoP = L.decnet_conv3d_packed_cout(Co)
+                    if CoP < 0:
+                        raise _lib.DecnetHipError("Conv3d with %d output channels is not supported "
+                                                  "(<= 224)" % Co)
+                    wp = torch.empty((27, Ci, CoP), dtype=torch.float32, device=dev)
+                    _lib.check(L.decnet_conv3d_pack_weight(w.data_ptr(), wp.data_ptr(), Co, Ci,
+                                                           stream), "decnet_conv3d_pack_weight")
+                    packed.append(dict(w=wp, scale=scale.contiguous(), shift=shift.contiguous(),
+                                       Ci=Ci, Co=Co, relu=1 if u.relu else 0, keep=w))
+                else:
+                    assert Co == 1
+                    packed.append(dict(w=w, scale=float(scale.item()), shift=float(shift.item()),
+                                       Ci=Ci, Co=1, relu=0))
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def _workspace(self, dev, n):
+        ws = self._ws.get(dev)
+        if ws is None or ws[0].numel() < n:
+            ws = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3)]
+            self._ws[dev] = ws
+        return ws
+
+    def run_ndhwc(self, x, want_reg=True, want_pred=True):
+        """x: channels-last cost volume [B,D,H,W,C].  Returns (reg [B,D,H,W] or None,
+        pred [B,H,W] or None).  The input buffer is not modified."""
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            raise NotImplementedError("CostRegNetNoDown on gfx950 is inference-only: call "
+                                      ".eval() and run under torch.no_grad()")
+        _chk("cost volume", x)
+        B, D, H, W, C = x.shape
+        P = self.prepare()
+        if P[0]["Ci"] != C:
+            raise ValueError("cost volume has %d channels, module expects %d" % (C, P[0]["Ci"]))
+        L = _lib.lib()
+        dev = x.device
+        a, b, c = self._workspace(dev, B * D * H * W * C)
+        reg = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_reg else None
+        pred = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+
+        def conv(i, src, dst, res=None):
+            p = P[i]
+            rc = L.decnet_conv3d_bn_act(src.data_ptr(), p["w"].data_ptr(), p["scale"].data_ptr(),
+                                        p["shift"].data_ptr(), res.data_ptr() if res is not None else None,
+                                        dst.data_ptr(), B, D, H, W, p["Ci"], p["Co"], p["relu"], st)
+            _lib.check(rc, "decnet_conv3d_bn_act[%d]" % i)
+
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            # CostRegNetNoDown.forward submodule.py:650-662
+            conv(0, x, a)
+            conv(1, a, c)                 # c = output0
+            conv(2, c, a)
+            conv(3, a, b)
+            conv(4, b, a, res=c)          # conv1(output0) + output0
+            conv(5, a, b)
+            conv(6, b, c)
+            p = P[7]
+            rc = L.decnet_conv3d_cout1_softargmax(
+                c.data_ptr(), p["w"].data_ptr(), p["scale"], p["shift"],
+                reg.data_ptr() if reg is not None else None, pred.data_ptr(), B, D, H, W, p["Ci"], st)
+            _lib.check(rc, "decnet_conv3d_cout1_softargmax")
+        return reg, (pred if want_pred else None)
+
+    def forward(self, x):
+        reg, _ = self.run_ndhwc(_to_ndhwc(x), want_reg=True, want_pred=False)
+        return reg
+
+
+def disparity_regression(cost_vol, disp_samples):
+    """submodule.py:766-777: softmax over dim 1, expectation of disp_samples.  N*S*H*W -> N*H*W"""
+    cost_vol = cost_vol.contiguous()
+    _chk("cost_vol", cost_vol)
+    B, S, H, W = cost_vol.shape
+    disp_samples = disp_samples.expand(B, S, H, W).contiguous()
+    _chk("disp_samples", disp_samples, (B, S, H, W))
+    pred = torch.empty((B, H, W), dtype=torch.float32, device=cost_vol.device)
+    with torch.cuda.device(cost_vol.device):
+        rc = _lib.lib().decnet_disparity_regression(cost_vol.data_ptr(), disp_samples.data_ptr(),
+                                                    pred.data_ptr(), B, S, H, W, _stream(cost_vol))
+    _lib.check(rc, "decnet_disparity_regression")
+    return pred
+
+
+class Stage0(nn.Module):
+    """The whole stage-0 branch of SparseDenseNetRefinementMask.forward (:127-137) as one
+    call: get_disp_samples -> GetCostVolume -> CostRegNetNoDown -> disparity_regression,
+    with no [B,C,D,H,W] tensor ever leaving the channels-last workspace."""
+
+    def __init__(self, cost_regularizer):
+        super(Stage0, self).__init__()
+        self.cost_regularizer = cost_regularizer
+        self._cv = {}
+
+    def forward(self, left_feature_map, right_feature_map, max_disp, return_reg=False):
+        left = left_feature_map.contiguous()
+        right = right_feature_map.contiguous()
+        B, C, H, W = left.shape
+        D = int(max_disp)
+        key = (left.device, B, D, H, W, C)
+        cv = self._cv.get(key)
+        if cv is None:
+            cv = torch.empty((B, D, H, W, C), dtype=torch.float32, device=left.device)
+            self._cv = {key: cv}
+        costvol_ndhwc(left, right, D, out=cv)
+        reg, pred = self.cost_regularizer.run_ndhwc(cv, want_reg=return_reg, want_pred=True)
+        return (pred, reg) if return_reg else pred

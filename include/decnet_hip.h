@@ -1,0 +1,144 @@
+/*
+ * include/decnet_hip.h -- C ABI of libdecnet_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for DecNet's data-parallel hot path.  Every entry point takes
+ * plain device pointers, sizes and a hipStream_t passed as void*; no torch types.
+ * Each one names the reference interface (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - All tensors are fp32, dense, row-major in the layout stated per argument.
+ *     Feature maps are NCHW, masks / per-pixel planes are N,H,W  (functions/SpaMat.py:13-16).
+ *   - Device pointers must be valid on the device that is current when the call is made;
+ *     work is enqueued on `stream` (NULL = the null stream) and the call returns
+ *     immediately (asynchronous, like the reference's launches SM_kernel.cu:384-386).
+ *   - Re-entrant: no global mutable state; safe to call from one host thread per GPU
+ *     (the reference is driven that way by DataParallel, eval.py:146).
+ *   - Outputs are fully written by the callee (entries the reference leaves to the
+ *     caller's zero fill, functions/SpaMat.py:25-27,42-43, are written as 0), so the
+ *     caller does not have to clear them.  Inputs are never modified.
+ *   - Return value: 0 (DECNET_OK) on success, a negative DECNET_ERR_* for rejected
+ *     arguments (nothing is enqueued), or a positive hipError_t from the launch.
+ *     (The reference's pybind functions always return 1 and check nothing,
+ *     SM_cuda.cpp:7-27; the Python shim in decnet_amd/ext.py restores that `1`.)
+ */
+#ifndef DECNET_HIP_H
+#define DECNET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DECNET_OK 0
+#define DECNET_ERR_NULL_POINTER (-1)
+#define DECNET_ERR_BAD_SHAPE (-2)     /* non-positive dim, max_disp < 1, index space > 2^31 */
+#define DECNET_ERR_UNSUPPORTED (-3)   /* shape does not fit the kernels' LDS tiling */
+
+/* Library / build identification: "decnet_hip <version> gfx950". */
+const char *decnet_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * SpaMat forward.  Replaces sparse_matching_cuda_forward (SM_cuda.cpp:7-15), i.e. the two
+ * launches get_max_cost + sparse_matching_forward (SM_kernel.cu:22-60, 76-125, 359-387).
+ *   ref, tar            [B,C,H,W]  left / right feature maps
+ *   ref_mask, tar_mask  [B,H,W]    0 = off, anything else = on
+ *   output              [B,H,W]    soft-argmax disparity   (0 where ref_mask == 0)
+ *   sum_similarities    [B,H,W]    1e-6 + sum_d exp(cost_d - max_cost)
+ *   max_cost            [B,H,W]    max(1e-6, max_d cost_d)
+ *   max_disp            candidates d in [0, min(max_disp, x+1))
+ * ------------------------------------------------------------------------------------- */
+int decnet_spamat_forward(const float *ref, const float *tar, const float *ref_mask,
+                          const float *tar_mask, float *output, float *sum_similarities,
+                          float *max_cost, int B, int C, int H, int W, int max_disp,
+                          void *stream);
+
+/* SpaMat backward.  Replaces sparse_matching_cuda_backward (SM_cuda.cpp:17-27): the launches
+ * sparse_matching_ref_backward + sparse_matching_tar_backward (SM_kernel.cu:143-195, 300-355,
+ * 389-429).  grad_ref / grad_tar [B,C,H,W] are fully written.                              */
+int decnet_spamat_backward(const float *ref, const float *tar, const float *ref_mask,
+                           const float *tar_mask, const float *output,
+                           const float *sum_similarities, const float *max_cost,
+                           const float *grad_output, float *grad_ref, float *grad_tar,
+                           int B, int C, int H, int W, int max_disp, void *stream);
+
+/* SpaVar forward.  Replaces sparse_var_cuda_forward (SV_cuda.cpp:7-17; kernels
+ * SV_kernel.cu:22-60, 76-124, 329-359): output = (1e-6 + sum_d e_d (d - disparity)^2) / S. */
+int decnet_spavar_forward(const float *ref, const float *tar, const float *ref_mask,
+                          const float *tar_mask, const float *disparity, float *output,
+                          float *sum_similarities, float *max_cost, int B, int C, int H, int W,
+                          int max_disp, void *stream);
+
+/* SpaVar backward.  Replaces sparse_var_cuda_backward (SV_cuda.cpp:19-32; kernels
+ * SV_kernel.cu:142-325, 361-410).  grad_disparity [B,H,W].                                */
+int decnet_spavar_backward(const float *ref, const float *tar, const float *ref_mask,
+                           const float *tar_mask, const float *disparity, const float *output,
+                           const float *sum_similarities, const float *max_cost,
+                           const float *grad_output, float *grad_ref, float *grad_tar,
+                           float *grad_disparity, int B, int C, int H, int W, int max_disp,
+                           void *stream);
+
+/* Fused SpaMat + SpaVar forward for the only way the model uses SpaVar
+ * (SparseDenseNetRefinementMask.py:183-192: same features and masks, disparity = SpaMat's
+ * output, under no_grad).  One read of ref/tar instead of four.
+ *   output, variance, sum_similarities, max_cost   [B,H,W]                                 */
+int decnet_spamatvar_forward(const float *ref, const float *tar, const float *ref_mask,
+                             const float *tar_mask, float *output, float *variance,
+                             float *sum_similarities, float *max_cost, int B, int C, int H,
+                             int W, int max_disp, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Stage 0 (coarsest level): dense cost volume -> 3-D conv aggregation -> soft-argmax.
+ * Internal activation layout is channels-last  [B, D, H, W, C]  ("NDHWC").
+ * ------------------------------------------------------------------------------------- */
+
+/* Cost volume, cost_func="cor", warp_ope="homgrp" with disp_samples = arange(D)
+ * (get_disp_samples submodule.py:389-390; GetCostVolume submodule.py:479-522, 532-562):
+ *   cost[b,d,y,x,c] = (x >= d ? left[b,c,y,x] : 0) * bilinear(right[b,c]; xs, ys)
+ *   xs = (x-d)*W/(W-1) - 0.5,  ys = y*H/(H-1) - 0.5, zero padding   (grid_sample with
+ *   align_corners=False on align_corners=True-normalised coordinates).
+ *   left,right [B,C,H,W];  cost_ndhwc [B,D,H,W,C].                                         */
+int decnet_costvol_forward(const float *left, const float *right, float *cost_ndhwc, int B,
+                           int C, int H, int W, int D, void *stream);
+
+/* Repack one Conv3d weight  [Co,Ci,3,3,3] (torch layout, submodule.py:109) into the kernels'
+ * [27, Ci, CoP] layout, CoP = decnet_conv3d_packed_cout(Co), zero padded.                  */
+int decnet_conv3d_packed_cout(int Co);
+int decnet_conv3d_pack_weight(const float *w_oidhw, float *w_packed, int Co, int Ci,
+                              void *stream);
+
+/* One Conv3dUnit in eval mode (submodule.py:115-123: Conv3d k3 s1 p1 no bias ->
+ * BatchNorm3d(running stats) -> ReLU), channels-last in and out:
+ *   y = act(conv(x) * scale[co] + shift[co]) (+ residual)
+ *   scale = gamma / sqrt(var + eps),  shift = beta - mean * scale   (caller folds BN)
+ *   x [B,D,H,W,Ci];  w_packed from decnet_conv3d_pack_weight;  y [B,D,H,W,Co];
+ *   residual: NULL or [B,D,H,W,Co], added after the activation (CostRegNetNoDown.forward
+ *   submodule.py:656: conv1(o0) + o0);  relu: 0/1.                                         */
+int decnet_conv3d_bn_act(const float *x, const float *w_packed, const float *scale,
+                         const float *shift, const float *residual, float *y, int B, int D,
+                         int H, int W, int Ci, int Co, int relu, void *stream);
+
+/* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
+ * over disp_samples = arange(D) (submodule.py:766-777):
+ *   reg[b,d,y,x]  = conv(x)[b,d,y,x] * scale + shift        (optional output, may be NULL)
+ *   pred[b,y,x]   = sum_d softmax_d(reg)[d] * d
+ *   x [B,D,H,W,Ci];  w [1,Ci,3,3,3] torch layout (no repack needed).                       */
+int decnet_conv3d_cout1_softargmax(const float *x, const float *w_oidhw, float scale,
+                                   float shift, float *reg, float *pred, int B, int D, int H,
+                                   int W, int Ci, void *stream);
+
+/* disparity_regression for arbitrary samples (submodule.py:766-777):
+ *   cost, samples [B,S,H,W] -> pred [B,H,W]                                                */
+int decnet_disparity_regression(const float *cost, const float *samples, float *pred, int B,
+                                int S, int H, int W, void *stream);
+
+/* Layout helpers between the reference's [B,C,D,H,W] and the internal [B,D,H,W,C]. */
+int decnet_ncdhw_to_ndhwc(const float *src, float *dst, int B, int C, int D, int H, int W,
+                          void *stream);
+int decnet_ndhwc_to_ncdhw(const float *src, float *dst, int B, int C, int D, int H, int W,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DECNET_HIP_H */

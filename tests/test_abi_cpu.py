@@ -1,0 +1,76 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/decnet_hip.h declares; argument validation happens before anything is launched;
+the product package never touches oracle/."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "decnet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(decnet_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from decnet_amd import build
+    path = build.build()                      # hipcc cross-compiles for gfx950 without a GPU
+    return ctypes.CDLL(path)
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("decnet_spamat_forward", "decnet_spamat_backward", "decnet_spavar_forward",
+              "decnet_spavar_backward", "decnet_spamatvar_forward", "decnet_costvol_forward",
+              "decnet_conv3d_bn_act", "decnet_conv3d_cout1_softargmax", "decnet_version"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for s in declared_symbols():
+        assert hasattr(lib, s), "libdecnet_hip.so does not export %s" % s
+
+
+def test_python_binding_covers_every_declared_symbol():
+    from decnet_amd import _lib
+    assert sorted(list(_lib.SIGNATURES) + ["decnet_version"]) == declared_symbols()
+
+
+def test_version_and_argument_validation_without_gpu(lib):
+    lib.decnet_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.decnet_version()
+    P, I = ctypes.c_void_p, ctypes.c_int
+    lib.decnet_spamat_forward.argtypes = [P] * 7 + [I] * 5 + [P]
+    one = ctypes.c_void_p(64)
+    # null pointer / bad shape are rejected before any HIP call
+    assert lib.decnet_spamat_forward(None, one, one, one, one, one, one, 1, 1, 1, 1, 1, None) == -1
+    assert lib.decnet_spamat_forward(one, one, one, one, one, one, one, 1, 1, 0, 1, 1, None) == -2
+    assert lib.decnet_spamat_forward(one, one, one, one, one, one, one, 1, 1, 1, 1, 0, None) == -2
+    assert lib.decnet_conv3d_packed_cout(216) == 224
+    assert lib.decnet_conv3d_packed_cout(300) == -1
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "decnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "liboracle" in txt \
+                        or "spamat_oracle" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, "product code references the oracle: %s" % bad
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    import decnet_amd
+    x = torch.zeros(1, 2, 3, 4)
+    m = torch.ones(1, 3, 4)
+    with pytest.raises(decnet_amd.DecnetHipError):
+        decnet_amd.SpaMat()(x, x, m, m, 2)

@@ -1,0 +1,183 @@
+"""Parity of the HIP SpaMat / SpaVar kernels against the CPU oracle.  -m gpu.
+
+Tolerances (fp32 path; north_star allows 1e-3 px MEAN abs diff on disparity maps):
+  max_cost          : 1e-5 relative  (same c-ordered fmaf chain -> normally bit-equal)
+  sum_similarities  : 2e-5 relative  (expf implementations differ by ~1 ulp per term)
+  disparity output  : max abs 2e-4 px + 1e-5 relative, and mean abs < 2e-5 px
+  variance          : 2e-4 relative + 2e-3 abs (values reach D^2 ~ 5e4)
+  gradients         : 2e-5 * max|grad| abs
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import decnet_amd  # noqa: F401  (fails loudly if libdecnet_hip.so is missing)
+    return torch.device("cuda:0")
+
+
+def make_case(seed, B, C, H, W, p_ref, p_tar, relu=True, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    L = torch.randn(B, C, H, W, generator=g) * scale
+    R = torch.randn(B, C, H, W, generator=g) * scale
+    if relu:
+        L, R = torch.relu(L), torch.relu(R)
+    rm = (torch.rand(B, H, W, generator=g) < p_ref).float()
+    tm = (torch.rand(B, H, W, generator=g) < p_tar).float()
+    return L, R, rm, tm
+
+
+def check_fwd(o, s, m, out, ssum, mx, D):
+    out, ssum, mx = (t.cpu().numpy() for t in (out, ssum, mx))
+    np.testing.assert_allclose(mx, m, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ssum, s, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(out, o, rtol=1e-5, atol=2e-4)
+    assert np.abs(out - o).mean() < 2e-5
+
+
+CASES = [
+    # B, C, H,  W,   D,  p_ref, p_tar
+    (2, 8, 5, 300, 216, 1.0, 1.0),      # stage-3 like: W > 256 (2 tiles), D < W
+    (1, 8, 4, 243, 216, 0.5, 0.5),
+    (2, 24, 6, 81, 72, 0.9, 0.9),       # stage-2 like
+    (1, 72, 6, 27, 24, 0.4, 0.4),       # stage-1 like
+    (1, 8, 3, 100, 216, 1.0, 1.0),      # max_disp > W
+    (1, 3, 2, 7, 5, 1.0, 0.5),          # tiny, odd C
+    (2, 8, 7, 515, 40, 0.1, 0.1),       # sparse, ragged tiles
+    (1, 8, 2, 64, 64, 1.0, 0.0),        # no valid candidate anywhere -> 1.0 (S6)
+    (1, 8, 2, 64, 64, 0.0, 1.0),        # ref all off -> zeros
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,D,pr,pt", CASES)
+def test_spamat_forward_vs_oracle(dev, B, C, H, W, D, pr, pt):
+    import decnet_amd
+    L, R, rm, tm = make_case(11, B, C, H, W, pr, pt)
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    mod = decnet_amd.SpaMat()
+    out = mod(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), np.int64(D))      # numpy.int64: S13
+    # reach the saved intermediates through the ext-level entry point
+    from decnet_amd.ext import SpaMat as ext
+    o2, s2, m2 = (torch.full((B, H, W), 7.0, device=dev) for _ in range(3))    # NOT zero filled
+    assert ext.sparse_matching_cuda_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), o2, s2,
+                                            m2, D) == 1
+    assert torch.equal(out, o2)
+    check_fwd(o, s, m, o2, s2, m2, D)
+    if pr == 0.0:
+        assert float(o2.abs().max()) == 0 and float(s2.abs().max()) == 0
+    if pt == 0.0:
+        assert (o2.cpu().numpy()[rm.numpy() != 0] == 1.0).all()
+
+
+@pytest.mark.parametrize("B,C,H,W,D,pr,pt", CASES[:7])
+def test_spavar_and_fused_forward_vs_oracle(dev, B, C, H, W, D, pr, pt):
+    import decnet_amd
+    L, R, rm, tm = make_case(12, B, C, H, W, pr, pt)
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    g = torch.Generator().manual_seed(3)
+    mu = torch.from_numpy(o) + torch.randn(B, H, W, generator=g)
+    v, s2, m2 = oracle.spavar_forward(L, R, rm, tm, mu, D)
+    dL, dR, drm, dtm = (t.to(dev) for t in (L, R, rm, tm))
+    var = decnet_amd.SpaVar()(dL, dR, drm, dtm, mu.to(dev), D)
+    np.testing.assert_allclose(var.cpu().numpy(), v, rtol=2e-4, atol=2e-3)
+    # fused: disparity = SpaMat output of the same launch
+    fo, fv, fs, fm = decnet_amd.spamatvar_forward(dL, dR, drm, dtm, D)
+    check_fwd(o, s, m, fo, fs, fm, D)
+    v_o, _, _ = oracle.spavar_forward(L, R, rm, tm, o, D)
+    # the variance is taken around the GPU's own disparity (differs from the oracle's by
+    # <= 2e-4 px), d(var)/d(mu) = 2 (mu - mean) = 0 at mu = mean -> second order only
+    np.testing.assert_allclose(fv.cpu().numpy(), v_o, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("B,C,H,W,D,pr,pt", [(2, 8, 4, 130, 48, 0.7, 0.7), (1, 24, 3, 81, 72, 0.9, 0.8),
+                                             (1, 72, 4, 27, 24, 0.5, 0.5), (1, 8, 2, 300, 216, 1.0, 1.0),
+                                             (1, 5, 2, 9, 12, 1.0, 1.0)])
+def test_backward_vs_oracle(dev, B, C, H, W, D, pr, pt):
+    import decnet_amd
+    L, R, rm, tm = make_case(13, B, C, H, W, pr, pt, relu=False, scale=0.5)
+    g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(5))
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    gl, gr = oracle.spamat_backward(L, R, rm, tm, o, s, m, g, D)
+    dL, dR = L.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+    out = decnet_amd.SpaMatFunction.apply(dL, dR, rm.to(dev), tm.to(dev), D)
+    out.backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 2e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 2e-5 * sc
+    # SpaVar: three gradients, disparity differentiable
+    mu = torch.from_numpy(o) + 0.25
+    v, s2, m2 = oracle.spavar_forward(L, R, rm, tm, mu, D)
+    gl, gr, gd = oracle.spavar_backward(L, R, rm, tm, mu, v, s2, m2, g, D)
+    dL, dR = L.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+    dmu = mu.to(dev).requires_grad_()
+    var = decnet_amd.SpaVarFunction.apply(dL, dR, rm.to(dev), tm.to(dev), dmu, D)
+    var.backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()), float(np.abs(gd).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 5e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
+    assert np.abs(dmu.grad.cpu().numpy() - gd).max() < 5e-5 * sc
+
+
+def test_net_callsite_golden(dev, golden_dir):
+    """Arrays recorded at the sparse_matching / sparse_var call sites of the reference graph."""
+    import decnet_amd
+    d = np.load(os.path.join(golden_dir, "net_54x243.npz"))
+    for i in (1, 2, 3):
+        args = [torch.from_numpy(d["sm%d_%s" % (i, n)]).to(dev) for n in ("ref", "tar", "rmask", "tmask")]
+        D = d["sm%d_max_disp" % i][()]
+        assert isinstance(D, np.int64)
+        out = decnet_amd.SpaMat()(*args, D)
+        ref_out = d["sm%d_out" % i]
+        assert np.abs(out.cpu().numpy() - ref_out).max() < 2e-4
+        assert np.abs(out.cpu().numpy() - ref_out).mean() < 2e-5
+        var = decnet_amd.SpaVar()(*args, torch.from_numpy(d["sv%d_disparity" % i]).to(dev), D)
+        np.testing.assert_allclose(var.cpu().numpy(), d["sv%d_out" % i], rtol=2e-4, atol=2e-3)
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 size (B=8, 972x540, D=216, stage 3): size-independent properties."""
+    import decnet_amd
+    B, C, H, W, D = 8, 8, 540, 972, 216
+    g = torch.Generator(device=dev).manual_seed(20)
+    L = torch.relu(torch.randn(B, C, H, W, device=dev, generator=g))
+    R = torch.relu(torch.randn(B, C, H, W, device=dev, generator=g))
+    rm = (torch.rand(B, H, W, device=dev, generator=g) < 0.1).float()
+    tm = (torch.rand(B, H, W, device=dev, generator=g) < 0.1).float()
+    o, v, s, m = decnet_amd.spamatvar_forward(L, R, rm, tm, D)
+    assert float(o[rm == 0].abs().max()) == 0 and float(v[rm == 0].abs().max()) == 0
+    on = rm != 0
+    assert float(o[on].min()) >= 0 and float(o[on].max()) <= D - 1 + 1e-3      # expectation of d
+    assert float(v[on].min()) >= 0
+    assert float(s[on].min()) >= np.float32(1e-6) and float(m[on].min()) >= np.float32(1e-6)
+    # batch independence (the property the multi-GPU sharding relies on)
+    o1, v1, _, _ = decnet_amd.spamatvar_forward(L[3:4].contiguous(), R[3:4].contiguous(),
+                                                rm[3:4].contiguous(), tm[3:4].contiguous(), D)
+    assert torch.equal(o1[0], o[3]) and torch.equal(v1[0], v[3])
+    # a random sample of rows against the oracle
+    rows = [(0, 0), (7, 539), (4, 271)]
+    for b, y in rows:
+        oo, ss, mm = oracle.spamat_forward(L[b:b + 1, :, y:y + 1].cpu(), R[b:b + 1, :, y:y + 1].cpu(),
+                                           rm[b:b + 1, y:y + 1].cpu(), tm[b:b + 1, y:y + 1].cpu(), D)
+        assert np.abs(o[b, y].cpu().numpy() - oo[0, 0]).max() < 2e-4
+
+
+def test_rejects_bad_arguments(dev):
+    import decnet_amd
+    L, R, rm, tm = (t.to(dev) for t in make_case(1, 1, 4, 2, 8, 1.0, 1.0))
+    with pytest.raises(decnet_amd.DecnetHipError):
+        decnet_amd.SpaMat()(L.cpu(), R.cpu(), rm.cpu(), tm.cpu(), 4)            # no CPU fallback
+    with pytest.raises(AssertionError):
+        decnet_amd.SpaMat()(L.transpose(2, 3), R, rm, tm, 4)                    # SpaMat.py:21
+    with pytest.raises(TypeError):
+        decnet_amd.SpaMat()(L.double(), R.double(), rm, tm, 4)
+    with pytest.raises(ValueError):
+        decnet_amd.SpaMat()(L, R, rm[:, :1], tm, 4)
