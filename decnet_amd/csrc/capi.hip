@@ -13,6 +13,35 @@ int decnet_rowtile_backward(int var, const float *ref, const float *tar, const f
                             int W, int max_disp, hipStream_t stream);
 int decnet_check_spamat_args(const void *const *ptrs, int n, int B, int C, int H, int W,
                              int max_disp);
+// kernels in spamat_mfma.hip (banded cost tiles on the matrix cores)
+int decnet_mfma_forward(int mode, const float *ref, const float *tar, const float *rmask,
+                        const float *tmask, const float *disparity, float *out, float *var_out,
+                        float *sum_sim, float *max_cost, int B, int C, int H, int W, int max_disp,
+                        hipStream_t stream);
+
+#include <stdlib.h>
+#include <string.h>
+
+// Forward dispatch: the MFMA band kernel; the row-tile kernel covers what it cannot
+// (band wider than 12 tiles, LDS overflow).  DECNET_SPAMAT_KERNEL=rowtile|mfma pins one
+// variant (read once; used by the A/B benchmarks and the parity tests of both variants).
+static int forward_dispatch(int mode, const float *ref, const float *tar, const float *rmask,
+                            const float *tmask, const float *disparity, float *out, float *var_out,
+                            float *sum_sim, float *max_cost, int B, int C, int H, int W,
+                            int max_disp, hipStream_t stream) {
+    static const int pinned = [] {
+        const char *e = getenv("DECNET_SPAMAT_KERNEL");
+        if (!e) return 0;
+        return !strcmp(e, "rowtile") ? 1 : (!strcmp(e, "mfma") ? 2 : 0);
+    }();
+    if (pinned != 1) {
+        int rc = decnet_mfma_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
+                                     max_cost, B, C, H, W, max_disp, stream);
+        if (rc != DECNET_ERR_UNSUPPORTED || pinned == 2) return rc;
+    }
+    return decnet_rowtile_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
+                                  max_cost, B, C, H, W, max_disp, stream);
+}
 
 extern "C" {
 
@@ -24,7 +53,7 @@ int decnet_spamat_forward(const float *ref, const float *tar, const float *ref_m
     const void *p[] = {ref, tar, ref_mask, tar_mask, output, sum_similarities, max_cost};
     int rc = decnet_check_spamat_args(p, 7, B, C, H, W, max_disp);
     if (rc) return rc;
-    return decnet_rowtile_forward(0, ref, tar, ref_mask, tar_mask, nullptr, output, nullptr,
+    return forward_dispatch(0, ref, tar, ref_mask, tar_mask, nullptr, output, nullptr,
                                   sum_similarities, max_cost, B, C, H, W, max_disp,
                                   (hipStream_t)stream);
 }
@@ -36,7 +65,7 @@ int decnet_spavar_forward(const float *ref, const float *tar, const float *ref_m
     const void *p[] = {ref, tar, ref_mask, tar_mask, disparity, output, sum_similarities, max_cost};
     int rc = decnet_check_spamat_args(p, 8, B, C, H, W, max_disp);
     if (rc) return rc;
-    return decnet_rowtile_forward(1, ref, tar, ref_mask, tar_mask, disparity, nullptr, output,
+    return forward_dispatch(1, ref, tar, ref_mask, tar_mask, disparity, nullptr, output,
                                   sum_similarities, max_cost, B, C, H, W, max_disp,
                                   (hipStream_t)stream);
 }
@@ -48,7 +77,7 @@ int decnet_spamatvar_forward(const float *ref, const float *tar, const float *re
     const void *p[] = {ref, tar, ref_mask, tar_mask, output, variance, sum_similarities, max_cost};
     int rc = decnet_check_spamat_args(p, 8, B, C, H, W, max_disp);
     if (rc) return rc;
-    return decnet_rowtile_forward(2, ref, tar, ref_mask, tar_mask, nullptr, output, variance,
+    return forward_dispatch(2, ref, tar, ref_mask, tar_mask, nullptr, output, variance,
                                   sum_similarities, max_cost, B, C, H, W, max_disp,
                                   (hipStream_t)stream);
 }
