@@ -5,7 +5,10 @@ There is no CPU fallback: if the library is missing or a call fails this module 
 import ctypes
 import os
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _DEFAULT_LIB
+
+# DECNET_HIP_LIB points the loader at another build of the same ABI (diagnostic / ablation builds)
+LIB_PATH = os.environ.get("DECNET_HIP_LIB", _DEFAULT_LIB)
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
