@@ -78,13 +78,13 @@ def make_regularizer(C, dev, seed=17):
 class HotPath:
     def __init__(self, B, dev, density, world):
         import decnet_amd
-        self.decnet = decnet_amd
+        from decnet_amd import dist as decnet_dist
+        self.decnet, self.dist = decnet_amd, decnet_dist
         self.B, self.dev, self.world = B, dev, world
         self.feats, self.masks = make_inputs(B, dev, density, seed=1000 * (int(os.environ.get("RANK", 0)) + 1))
         self.reg = make_regularizer(STAGES[0][0], dev)
         self.stage0 = decnet_amd.Stage0(self.reg)
         self.outs = [tuple(torch.empty(B, H, W, device=dev) for _ in range(4)) for (_, H, W, _) in STAGES[1:]]
-        self.gathered = torch.empty(world * B, PAD_H, PAD_W, device=dev) if world > 1 else None
         self.ev = None
 
     def step(self, events=None):
@@ -103,8 +103,8 @@ class HotPath:
             if events is not None and s == 3:
                 events["s3_end"].record()
         disp = self.outs[2][0]
-        if self.world > 1:
-            torch.distributed.all_gather_into_tensor(self.gathered, disp)
+        if self.world > 1:       # one RCCL all-gather of the per-rank disparity maps
+            disp = self.dist.gather_disparity(disp, n_pairs=self.world * self.B)
         return pred0, disp
 
 

@@ -12,17 +12,22 @@
 // Conv3d as implicit GEMM:  Y[M, Co] = sum_{tap, ci} X[shift_tap(m), ci] * Wp[tap, ci, co],
 // M = B*D*H*W output positions.  fp32 in / fp32 accumulate on the matrix cores
 // (v_mfma_f32_16x16x4_f32: exact fp32 fma chain, no reduced precision anywhere).
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DECNET_CONV_ABLATE
+#define DECNET_CONV_ABLATE 0   // diagnostic builds only (results wrong by construction):
+#endif                         // 1 no HBM/L2 prefetch, 2 no MFMA, 3 no per-step barrier, 4 no LDS staging
+
 namespace {
 
 constexpr int CONV_BN = 224;   // Co tile, 14 MFMA columns-of-16 (216 -> 224, 3.6 % padding)
-constexpr int CONV_BK = 24;    // 216 = 9 * 24
-constexpr int A_PITCH = 26;    // == 2 (mod 4): the 32 lanes (row i, k-quad kq<2) hit 32 banks
 constexpr int B_PITCH = 240;   // == 16 (mod 32): rows kq, kq+1 land on opposite bank halves
-constexpr int CONV_THREADS = 256;
+// A tile pitch is BK + 2 (== 2 mod 4): the 32 lanes (row i, k-quad kq < 2) hit 32 distinct banks
 
 // ----------------------------------- cost volume ---------------------------------------
 // cost[b,d,y,x,c] = (x >= d ? L[b,c,y,x] : 0) * bilinear(R[b,c]; ix, iy), zero padding.
@@ -76,96 +81,111 @@ __global__ void pack_weight(const float *__restrict__ w, float *__restrict__ wp,
 }
 
 // ------------------------------ Conv3d k3 s1 p1 implicit GEMM --------------------------
-// Workgroup: 256 threads = 4 waves as 2 (M) x 2 (N); tile BM x 224; wave tile (BM/2) x 112
-// = TM x 7 MFMA tiles of 16x16.  K loop: 27 taps x ceil(Ci/24) chunks, LDS double
-// buffered, next chunk prefetched global->registers while the current one is on the MFMAs.
-// LDS: As[2][BM][26] (k contiguous, as in HBM) | Bs[2][24][240] (co contiguous).
-template <int BM>
-__global__ __launch_bounds__(CONV_THREADS) void conv3d_k3_igemm(
+// Workgroup: WM x 2 waves (WM = 4: 512 threads, tile 192 x 224; WM = 2: 256 threads, 96 x 224);
+// every wave owns a 48 x 112 sub-tile = 3 x 7 MFMA tiles of 16x16 (84 accumulator VGPRs), so two
+// waves share each SIMD: while one wave computes addresses, stores its staged operands or sits at
+// the barrier, the other keeps the matrix pipe busy.
+// K loop: 27 taps x ceil(Ci/BK) chunks.  LDS is double buffered; the next chunk is fetched
+// HBM/L2 -> registers with bounds-checked buffer loads (padding taps and the M tail read as 0 by
+// pointing their offset out of range, no branches) while the current chunk is on the MFMAs.
+// LDS: As[2][BM][BK+2] (k contiguous, as in HBM) | Bs[2][BK][240] (co contiguous).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+    i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z),
+                       __int_as_float(v.w));
+}
+
+template <int WM, int BK>
+__global__ __launch_bounds__(WM * 128) void conv3d_k3_igemm(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ y,
-    int D, int H, int W, int Ci, int Co, int relu, int M) {
-    constexpr int TM = BM / 32, TN = 7;
-    constexpr int A_F4 = BM * (CONV_BK / 4);
-    constexpr int A_PER_T = (A_F4 + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int B_F4 = CONV_BK * (CONV_BN / 4);
-    constexpr int B_PER_T = (B_F4 + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int A_TILE = BM * A_PITCH, B_TILE = CONV_BK * B_PITCH;
+    int D, int H, int W, int Ci, int Co, int relu, int M, int x_bytes, int w_bytes) {
+    constexpr int THREADS = WM * 128, BM = WM * 48, TM = 3, TN = 7;
+    constexpr int A_PITCH = BK + 2;
+    constexpr int A_F4 = BM * (BK / 4);
+    constexpr int A_PER_T = (A_F4 + THREADS - 1) / THREADS;
+    constexpr int B_F4 = BK * (CONV_BN / 4);
+    constexpr int B_PER_T = (B_F4 + THREADS - 1) / THREADS;
+    constexpr int A_TILE = BM * A_PITCH, B_TILE = BK * B_PITCH;
+    constexpr int OOB = 0x7fffffff;     // >= num_records: the buffer load returns zeros
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                 // 2 * A_TILE
     float *Bs = smem + 2 * A_TILE;    // 2 * B_TILE
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, w_bytes, 0x00020000);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i16 = lane & 15, kq = lane >> 4;
     const int m_block = blockIdx.x * BM;
 
-    // rows of the A tile this thread stages (same rows every K step)
+    // rows of the A tile this thread stages (the same rows every K step)
     int a_lds[A_PER_T];     // LDS offset (floats) or -1
-    int a_pos[A_PER_T];     // linear position index ((b*D+d)*H+y)*W+x
-    int a_dyx[A_PER_T];     // d<<20 | y<<10 | x
-    int a_q4[A_PER_T];      // 4*q: channel offset inside the chunk
+    int a_off[A_PER_T];     // byte offset of x[pos m][4q]
+    int a_tap[A_PER_T];     // bit t set <=> tap t of this output position is inside the volume
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
-        int idx = tid + i * CONV_THREADS;
-        int ml = idx / (CONV_BK / 4), q = idx - ml * (CONV_BK / 4);
+        int idx = tid + i * THREADS;
+        int ml = idx / (BK / 4), q = idx - ml * (BK / 4);
         int m = m_block + ml;
         bool ok = idx < A_F4 && m < M;
         a_lds[i] = idx < A_F4 ? ml * A_PITCH + 4 * q : -1;
-        a_q4[i] = 4 * q;
         int mm = ok ? m : 0;
         int xx = mm % W; int t = mm / W;
         int yy = t % H; t /= H;
         int dd = t % D;
-        a_pos[i] = mm;
-        a_dyx[i] = ok ? ((dd << 20) | (yy << 10) | xx) : -1;
+        a_off[i] = (mm * Ci + 4 * q) * 4;
+        int bits = 0;
+        if (ok) {
+            for (int tap = 0; tap < 27; ++tap) {
+                int zd = dd + tap / 9 - 1, zy = yy + (tap / 3) % 3 - 1, zx = xx + tap % 3 - 1;
+                if ((unsigned)zd < (unsigned)D && (unsigned)zy < (unsigned)H && (unsigned)zx < (unsigned)W)
+                    bits |= 1 << tap;
+            }
+        }
+        a_tap[i] = bits;
     }
-    int b_lds[B_PER_T], b_k[B_PER_T], b_q4[B_PER_T];
+    int b_lds[B_PER_T], b_off[B_PER_T];
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
-        int idx = tid + i * CONV_THREADS;
+        int idx = tid + i * THREADS;
         int kk = idx / (CONV_BN / 4), q = idx - kk * (CONV_BN / 4);
         b_lds[i] = idx < B_F4 ? kk * B_PITCH + 4 * q : -1;
-        b_k[i] = kk;
-        b_q4[i] = 4 * q;
+        b_off[i] = idx < B_F4 ? (kk * CONV_BN + 4 * q) * 4 : OOB;
     }
 
-    const int nchunk = (Ci + CONV_BK - 1) / CONV_BK;
+    const int nchunk = (Ci + BK - 1) / BK;
     const int nstep = 27 * nchunk;
+    const bool ragged = (Ci % BK) != 0;            // last chunk of a tap is partial
 
     float4 ra[A_PER_T], rb[B_PER_T];
     auto prefetch = [&](int s) {
-        int tap = s / nchunk, ci0 = (s - tap * nchunk) * CONV_BK;
+        int tap = s / nchunk, ci0 = (s - tap * nchunk) * BK;
         int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
-        int tap_off = (kd * H + kh) * W + kw;
+        int a_step = (((kd * H + kh) * W + kw) * Ci + ci0) * 4;
+        int b_step = (tap * Ci + ci0) * CONV_BN * 4;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int dyx = a_dyx[i];
-            if (dyx >= 0) {
-                int dd = (dyx >> 20) + kd, yy = ((dyx >> 10) & 1023) + kh, xx = (dyx & 1023) + kw;
-                int ci = ci0 + a_q4[i];
-                if ((unsigned)dd < (unsigned)D && (unsigned)yy < (unsigned)H &&
-                    (unsigned)xx < (unsigned)W && ci < Ci)
-                    v = *reinterpret_cast<const float4 *>(x + (size_t)(a_pos[i] + tap_off) * Ci + ci);
-            }
-            ra[i] = v;
+            bool ok = (a_tap[i] >> tap) & 1;
+            if (ragged) ok = ok && (ci0 + (a_lds[i] % A_PITCH) < Ci);
+            ra[i] = buf_load4(xr, ok ? a_off[i] + a_step : OOB);
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int ci = ci0 + b_k[i];
-            if (b_lds[i] >= 0 && ci < Ci)
-                v = *reinterpret_cast<const float4 *>(wp + ((size_t)tap * Ci + ci) * CONV_BN + b_q4[i]);
-            rb[i] = v;
+            bool ok = b_lds[i] >= 0;
+            if (ragged) ok = ok && (ci0 + b_lds[i] / B_PITCH < Ci);
+            rb[i] = buf_load4(wr, ok ? b_off[i] + b_step : OOB);
         }
     };
     auto stage = [&](int buf) {
         float *a = As + buf * A_TILE, *b = Bs + buf * B_TILE;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i)
-            if (a_lds[i] >= 0) {      // rows are 8-byte aligned (pitch 26), not 16
+            if (a_lds[i] >= 0) {      // rows are 8-byte aligned (pitch BK+2), not 16
                 *reinterpret_cast<float2 *>(a + a_lds[i]) = make_float2(ra[i].x, ra[i].y);
                 *reinterpret_cast<float2 *>(a + a_lds[i] + 2) = make_float2(ra[i].z, ra[i].w);
             }
@@ -183,15 +203,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_k3_igemm(
     prefetch(0);
     stage(0);
     __syncthreads();
-    const int a_row0 = (wm * (BM / 2) + i16) * A_PITCH + kq;
+    const int a_row0 = (wm * 48 + i16) * A_PITCH + kq;
     const int b_col0 = kq * B_PITCH + wn * (CONV_BN / 2) + i16;
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
+#if DECNET_CONV_ABLATE != 1
         if (s + 1 < nstep) prefetch(s + 1);
+#endif
         const float *a = As + buf * A_TILE + a_row0;
         const float *b = Bs + buf * B_TILE + b_col0;
 #pragma unroll
-        for (int kk = 0; kk < CONV_BK / 4; ++kk) {
+        for (int kk = 0; kk < BK / 4; ++kk) {
             float av[TM], bv[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * A_PITCH + kk * 4];
@@ -201,10 +223,18 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_k3_igemm(
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
+#if DECNET_CONV_ABLATE == 2
+                    acc[i][j][0] += av[i] + bv[j];
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+#endif
         }
+#if DECNET_CONV_ABLATE != 4
         if (s + 1 < nstep) stage(buf ^ 1);
+#endif
+#if DECNET_CONV_ABLATE != 3
         __syncthreads();
+#endif
     }
 
     // epilogue: BN (folded scale/shift) -> ReLU -> + residual.  C/D layout of 16x16x4:
@@ -218,7 +248,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_k3_igemm(
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int m = m_block + wm * (BM / 2) + i * 16 + kq * 4 + r;
+                int m = m_block + wm * 48 + i * 16 + kq * 4 + r;
                 if (m >= M) continue;
                 float v = fmaf(acc[i][j][r], sc, sh);
                 if (relu) v = fmaxf(v, 0.f);
@@ -316,18 +346,20 @@ __global__ void transpose_inner(const float *__restrict__ src, float *__restrict
     }
 }
 
-template <int BM>
+template <int WM, int BK>
 int launch_conv(const float *x, const float *wp, const float *scale, const float *shift,
                 const float *residual, float *y, int D, int H, int W, int Ci, int Co, int relu,
                 int M, hipStream_t stream) {
-    size_t lds = 4 * (size_t)(2 * BM * A_PITCH + 2 * CONV_BK * B_PITCH);
+    constexpr int BM = WM * 48;
+    size_t lds = 4 * (size_t)(2 * BM * (BK + 2) + 2 * BK * B_PITCH);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3d_k3_igemm<BM>,
+        hipError_t e = hipFuncSetAttribute((const void *)conv3d_k3_igemm<WM, BK>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(conv3d_k3_igemm<BM>, dim3(ceil_div(M, BM)), dim3(CONV_THREADS), lds, stream,
-                       x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M);
+    int x_bytes = (int)((size_t)M * Ci * 4), w_bytes = 27 * Ci * CONV_BN * 4;
+    hipLaunchKernelGGL((conv3d_k3_igemm<WM, BK>), dim3(ceil_div(M, BM)), dim3(WM * 128), lds, stream,
+                       x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, x_bytes, w_bytes);
     return decnet_launch_status();
 }
 
@@ -369,22 +401,27 @@ int decnet_conv3d_bn_act(const float *x, const float *wp, const float *scale, co
     if (Md * (Ci > Co ? Ci : Co) >= 2147483648.0 * 4) return DECNET_ERR_BAD_SHAPE;
     if (Md >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
     int M = (int)Md;
-    // tile height: fewest rounds over 256 CUs, ties -> taller tile (more weight reuse)
-    const int cands[4] = {192, 128, 96, 64};
-    int best = 192;
-    long best_cost = -1;
-    for (int i = 0; i < 4; ++i) {
-        long blocks = ceil_div(M, cands[i]);
-        long cost = ((blocks + 255) / 256) * cands[i];
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cands[i]; }
-    }
+    if (Md * Ci * 4 >= 2147483647.0 || 27.0 * Ci * CONV_BN * 4 >= 2147483647.0)
+        return DECNET_ERR_UNSUPPORTED;                 // 32-bit buffer offsets
+    // tile height: fewest rounds over the 256 CUs, ties -> the taller tile (more weight reuse,
+    // two waves per SIMD)
+    long r192 = (ceil_div(M, 192) + 255) / 256 * 192, r96 = (ceil_div(M, 96) + 255) / 256 * 96;
     hipStream_t s = (hipStream_t)stream;
-    switch (best) {
-        case 192: return launch_conv<192>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-        case 128: return launch_conv<128>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-        case 96: return launch_conv<96>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-        default: return launch_conv<64>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+    static const int pinned = [] {          // DECNET_CONV_TILE=192x36|192x24|96x24 (A/B benchmarks)
+        const char *e = getenv("DECNET_CONV_TILE");
+        if (!e) return 0;
+        return !strcmp(e, "192x36") ? 1 : !strcmp(e, "192x24") ? 2 : !strcmp(e, "96x24") ? 3 : 0;
+    }();
+    if (pinned == 1 && Ci % 36 == 0)
+        return launch_conv<4, 36>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+    if (pinned == 2) return launch_conv<4, 24>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+    if (pinned == 3) return launch_conv<2, 24>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+    if (r192 <= r96) {
+        if (Ci % 36 == 0)
+            return launch_conv<4, 36>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
+        return launch_conv<4, 24>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
     }
+    return launch_conv<2, 24>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
 }
 
 int decnet_conv3d_cout1_softargmax(const float *x, const float *w, float scale, float shift,

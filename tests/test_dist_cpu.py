@@ -1,0 +1,57 @@
+"""Multi-rank logic on CPU with the gloo backend (world_size 2 and 3): shard indices and the
+gather order that the 8-GPU RCCL path relies on."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from decnet_amd.dist import gather_disparity, shard_batch, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def _worker(rank, world, n_pairs, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W = 3, 5
+        full = torch.arange(n_pairs * H * W, dtype=torch.float32).reshape(n_pairs, H, W)
+        masks = [torch.ones(n_pairs, 2, 2) * torch.arange(n_pairs).view(-1, 1, 1)]
+        local, lmasks = shard_batch((full, masks))
+        s, e = shard_range(n_pairs, rank, world)
+        assert torch.equal(local, full[s:e]) and torch.equal(lmasks[0], masks[0][s:e])
+        pred = local * 2 + 1                        # stands in for the per-rank hot path
+        got = gather_disparity(pred, n_pairs=n_pairs)
+        assert torch.equal(got, full * 2 + 1), "gathered maps are not in pair order"
+        got2 = gather_disparity(pred)               # sizes discovered with a small all_gather
+        assert torch.equal(got2, full * 2 + 1)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_pairs,port", [(2, 8, 29611), (2, 5, 29612), (3, 4, 29613)])
+def test_shard_and_gather_gloo(world, n_pairs, port):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, n_pairs, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(ret.keys()) == list(range(world))
