@@ -17,14 +17,15 @@ int decnet_check_spamat_args(const void *const *ptrs, int n, int B, int C, int H
 int decnet_mfma_forward(int mode, const float *ref, const float *tar, const float *rmask,
                         const float *tmask, const float *disparity, float *out, float *var_out,
                         float *sum_sim, float *max_cost, int B, int C, int H, int W, int max_disp,
-                        hipStream_t stream);
+                        int allow_compact, hipStream_t stream);
 
 #include <stdlib.h>
 #include <string.h>
 
 // Forward dispatch: the MFMA band kernel; the row-tile kernel covers what it cannot
-// (band wider than 12 tiles, LDS overflow).  DECNET_SPAMAT_KERNEL=rowtile|mfma pins one
-// variant (read once; used by the A/B benchmarks and the parity tests of both variants).
+// (band wider than 18 tiles, LDS overflow).  DECNET_SPAMAT_KERNEL=rowtile|mfma|mfma_dense pins
+// one variant (read once; used by the A/B benchmarks and the parity tests of the variants);
+// mfma_dense = MFMA kernel with the sparse-row compaction path switched off.
 static int forward_dispatch(int mode, const float *ref, const float *tar, const float *rmask,
                             const float *tmask, const float *disparity, float *out, float *var_out,
                             float *sum_sim, float *max_cost, int B, int C, int H, int W,
@@ -32,12 +33,12 @@ static int forward_dispatch(int mode, const float *ref, const float *tar, const 
     static const int pinned = [] {
         const char *e = getenv("DECNET_SPAMAT_KERNEL");
         if (!e) return 0;
-        return !strcmp(e, "rowtile") ? 1 : (!strcmp(e, "mfma") ? 2 : 0);
+        return !strcmp(e, "rowtile") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "mfma_dense") ? 3 : 0;
     }();
     if (pinned != 1) {
         int rc = decnet_mfma_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
-                                     max_cost, B, C, H, W, max_disp, stream);
-        if (rc != DECNET_ERR_UNSUPPORTED || pinned == 2) return rc;
+                                     max_cost, B, C, H, W, max_disp, pinned != 3, stream);
+        if (rc != DECNET_ERR_UNSUPPORTED || pinned >= 2) return rc;
     }
     return decnet_rowtile_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
                                   max_cost, B, C, H, W, max_disp, stream);

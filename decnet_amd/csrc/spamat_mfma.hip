@@ -4,33 +4,31 @@
 // fuses the two the way the model uses them (SparseDenseNetRefinementMask.py:183-192).
 //
 // Why the matrix cores for an HBM-shaped op: at stage 3 (C=8, D=216) every byte of L/R
-// feeds 36 fp32 MACs + 4.5 exp, above the chip's fp32 ridge, so the pass is VALU-bound
-// unless the channel dot products leave the VALU.  cost[x'][x] = sum_c R[c][x'] L[c][x]
+// feeds 36 fp32 MACs + 4.5 exp, above the chip's fp32 ridge.  cost[x'][x] = sum_c R[c][x'] L[c][x]
 // over a 16x16 tile of (right pixel, left pixel) IS a K=C matrix product, and
 // v_mfma_f32_16x16x4_f32 evaluates it as the same c-ordered fp32 fma chain the reference
-// binary runs (exact fp32, no reduced precision), on a pipe that runs beside the VALU.
-// The VALU is left with the softmax: max, exp, and the moment sums.
+// binary runs (exact fp32, no reduced precision) with one operand register per 64 MACs
+// instead of one LDS read per MAC.
 //
-// Work decomposition
-//   workgroup (8 waves)  one segment of XT 16-pixel tiles of ONE image row (normally the
-//                        whole row: no halo is read twice).  R[C][HALO+SW] and the right
-//                        mask (as an additive 0 / -1e30 bias) are staged once in LDS with
-//                        16-byte row loads, all issued before the first is waited for.
-//                        L is NOT staged: every left element is used by exactly one tile,
-//                        so it goes HBM -> registers (prefetched one tile ahead).
-//   wave                 one 16-pixel left tile at a time: NT = ceil((D-1)/16)+1 cost tiles
-//                        of the disparity band, 4*NT costs per lane kept in registers
-//                        (accumulator layout: lane&15 = left pixel, 4*(lane>>4)+reg = right
-//                        pixel), then max / exp-sum / variance passes over registers and a
-//                        4-lane exchange.  <= 128 VGPRs so that 4 waves share a SIMD: one
-//                        wave alone issues a VALU op only every 4 cycles, and the matrix
-//                        pipe of one wave runs under the VALU passes of the others.
-//   right mask           one extra K-step of the MFMA chain adds 0 or -1e30 (SM_kernel.cu:48).
-//   disparity range      0 <= d < D only needs checking on the diagonal tile and the last
-//                        one or two tiles of the band (SM_kernel.cu:42).
+// One workgroup (8 waves) owns one segment (normally the whole row) of ONE image row.
+//   phase 1  both mask rows -> LDS; block-wide prefix counts of the active pixels.
+//   phase 2  R[C][HALO+SW] -> LDS with 16-byte row loads (all issued before the first store).
+//   phase 3  per row, one of two paths:
+//     DENSE    (>= 80 % of the candidate pairs active): a wave owns 16 consecutive left pixels;
+//              NT = ceil((D-1)/16)+1 cost tiles of the disparity band, 4*NT costs per lane in
+//              registers (lane&15 = left pixel, 4*(lane>>4)+reg = right pixel); d is affine
+//              in (tile, register, lane); the right mask is an additive 0 / -1e30 bias.
+//     COMPACT  (sparse masks): left pixels are grouped in aligned spans of S pixels (S chosen
+//              per row so that a span holds <= ~16 active pixels and its disparity window holds
+//              <= 16*(NT+1) active right pixels); a wave multiplies the 16 gathered active
+//              left pixels against 16-wide tiles of the COMPACTED list of active right pixels
+//              in the window, so work scales with density^2 and the pass becomes HBM-bound.
+//   Both paths then run max / exp-sum / variance passes over registers and a 4-lane exchange.
 //
-// This file is compiled with -fno-honor-nans (see build.py): without it every fmaxf on an
-// MFMA result costs an extra canonicalising v_max; NaN inputs give NaN/garbage rows either way.
+// <= 128 VGPRs: 4 waves share a SIMD (fp32 MFMA and VALU share the FP32 units on gfx950 --
+// measured, see DESIGN.md -- so occupancy hides latency, it does not add throughput).
+// Compiled with -fno-honor-nans (build.py): otherwise every fmaxf on an MFMA result costs an
+// extra canonicalising v_max.
 #include "common.h"
 
 #ifndef DECNET_ABLATE
@@ -45,7 +43,7 @@ enum { MODE_MAT = 0, MODE_VAR = 1, MODE_FUSED = 2 };
 
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int THREADS = 512;
+constexpr int THREADS = 512, NWAVE = THREADS / 64;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -63,11 +61,17 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, in
     return v;
 }
 
-// LDS layout (floats).  The channel pitch is == 16 (mod 32) so that the four channel rows an
-// MFMA operand fetch touches (lanes 0-15 / 16-31 / 32-47 / 48-63) never share a bank.
+// LDS layout (4-byte words).  The channel pitch RP is == 16 (mod 32) so that the four channel
+// rows an MFMA operand fetch touches (lanes 0-15 / 16-31 / 32-47 / 48-63) never share a bank.
+//   Rs [Cq][RP]   R[c][xs - HALO + j];  column RP-1 is kept zero (target of padded gathers)
+//   BX [RP]       dense: 0 / -1e30 bias of the right mask;  compact: compacted right indices
+//   RK [RP+4]     exclusive prefix count of active right pixels
+//   LM [SW+16]    dense: left mask;  compact: exclusive prefix count of active left pixels
+//   XL [SW]       compacted left positions
+//   WT [32]       scan scratch
 struct Layout {
-    int SW, HALO, RP, Cq;      // Cq = channels rounded up to a multiple of 4
-    int offR, offB, total;
+    int SW, HALO, RP, Cq;
+    int offR, offBX, offRK, offLM, offXL, offWT, total;
 };
 __host__ __device__ inline Layout make_layout(int C, int NT, int XT) {
     Layout l;
@@ -76,9 +80,151 @@ __host__ __device__ inline Layout make_layout(int C, int NT, int XT) {
     l.Cq = (C + 3) & ~3;
     l.RP = ((l.HALO + l.SW + 31) & ~31) + 16;
     l.offR = 0;
-    l.offB = l.offR + l.Cq * l.RP;
-    l.total = l.offB + l.RP;
+    l.offBX = l.offR + l.Cq * l.RP;
+    l.offRK = l.offBX + l.RP;
+    l.offLM = l.offRK + l.RP + 4;
+    l.offXL = l.offLM + l.SW + 16;
+    l.offWT = l.offXL + l.SW;
+    l.total = l.offWT + 32;
     return l;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Softmax passes over NTL cost tiles held in acc[].  DENSE: d = 16*m + dl - r (affine).
+// COMPACT: d = xlj - XR[16*(t0+m) + 4q + r] read from LDS.  Returns through references.
+template <int NTL, int MODE, bool COMPACT>
+__device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int D, int dl,
+                                               const float *__restrict__ lds, int bias_off, int xr_off,
+                                               int xlj, float mu_in,
+                                               float &mx_o, float &S_o, float &mu_o, float &var_o) {
+    int dlv = dl;
+    asm volatile("" : "+v"(dlv));   // opaque: otherwise LICM hoists every range compare out of the
+                                    // tile loop and spills their lane masks
+    // ---- pass 1: range 0 <= d < min(D, x+1) (SM_kernel.cu:42,46), max_cost (SM_kernel.cu:45-59)
+    float mx0 = 0.000001f, mx1 = 0.000001f;
+    // COMPACT: the right positions are re-read from LDS in every pass through a pointer the
+    // compiler cannot identify with the previous pass's (otherwise GVN keeps all 4*NTL of them
+    // live across the passes and the kernel spills)
+    // (LDS word offsets, made opaque per pass: see the COMPACT note above and pass 1's bias)
+    int xo1 = xr_off, bo1 = bias_off;
+    asm volatile("" : "+v"(xo1), "+v"(bo1));
+    const int *xp1 = reinterpret_cast<const int *>(lds) + xo1;
+    const float *bp1 = lds + bo1;
+#pragma unroll
+    for (int m = 0; m < NTL; ++m) {
+        if (m < ntile) {
+            if (COMPACT) {
+                const int4 p = *reinterpret_cast<const int4 *>(xp1 + 16 * m);
+                acc[m][0] = (unsigned)(xlj - p.x) < (unsigned)D ? acc[m][0] : NEG_BIG;
+                acc[m][1] = (unsigned)(xlj - p.y) < (unsigned)D ? acc[m][1] : NEG_BIG;
+                acc[m][2] = (unsigned)(xlj - p.z) < (unsigned)D ? acc[m][2] : NEG_BIG;
+                acc[m][3] = (unsigned)(xlj - p.w) < (unsigned)D ? acc[m][3] : NEG_BIG;
+            } else {
+                // right mask (SM_kernel.cu:48) as an additive 0 / -1e30 bias, read here (not
+                // beside the MFMAs) so that only one tile's worth is live at a time
+                const float4 bz = *reinterpret_cast<const float4 *>(bp1 - 16 * m);
+                acc[m][0] += bz.x; acc[m][1] += bz.y; acc[m][2] += bz.z; acc[m][3] += bz.w;
+                if (m == 0 || 16 * m + 15 >= D) {
+                    asm volatile("" ::: "memory");  // keep a real scalar branch (no if-conversion)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = 16 * m + dlv - r;
+                        acc[m][r] = (unsigned)d >= (unsigned)D ? NEG_BIG : acc[m][r];
+                    }
+                }
+            }
+            mx0 = fmaxf(fmaxf(mx0, acc[m][0]), acc[m][1]);
+            mx1 = fmaxf(fmaxf(mx1, acc[m][2]), acc[m][3]);
+        }
+    }
+    float mx = fmaxf(mx0, mx1);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // ---- pass 2: e = exp(cost - max) (one fma: cost*log2e - max*log2e), S, T (SM_kernel.cu:100-122)
+    const float nm = -mx * LOG2E;
+    float S0 = 0.f, S1 = 0.f, T0 = 0.f, T1 = 0.f;
+    int xo2 = xr_off;
+    asm volatile("" : "+v"(xo2));
+    const int *xp2 = reinterpret_cast<const int *>(lds) + xo2;
+#pragma unroll
+    for (int m = 0; m < NTL; ++m) {
+        if (m < ntile) {
+            int4 p;
+            if (COMPACT) p = *reinterpret_cast<const int4 *>(xp2 + 16 * m);
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                float e0 = fast_exp2(fmaf(acc[m][r], LOG2E, nm));
+                float e1 = fast_exp2(fmaf(acc[m][r + 1], LOG2E, nm));
+                acc[m][r] = e0;
+                acc[m][r + 1] = e1;
+                S0 += e0;
+                S1 += e1;
+                if (MODE != MODE_VAR) {
+                    if (COMPACT) {
+                        T0 = fmaf(e0, (float)(xlj - (r == 0 ? p.x : p.z)), T0);
+                        T1 = fmaf(e1, (float)(xlj - (r == 0 ? p.y : p.w)), T1);
+                    } else {
+                        T0 = fmaf(e0, (float)(16 * m - r), T0);
+                        T1 = fmaf(e1, (float)(16 * m - r - 1), T1);
+                    }
+                }
+            }
+        }
+    }
+    const float dlf = (float)dl;
+    float Sl = S0 + S1;
+    float Tl = COMPACT ? T0 + T1 : fmaf(dlf, Sl, T0 + T1);      // dense: d = (16m - r) + dl
+    Sl += __shfl_xor(Sl, 16);
+    Sl += __shfl_xor(Sl, 32);
+    const float S = Sl + 0.000001f;
+    float mu = mu_in;
+    if (MODE != MODE_VAR) {
+        Tl += __shfl_xor(Tl, 16);
+        Tl += __shfl_xor(Tl, 32);
+        mu = (Tl + 0.000001f) / S;
+    }
+    // ---- pass 3: V = sum e*(d-mu)^2  (SV_kernel.cu:100-121)
+    float var = 0.f;
+    if (MODE != MODE_MAT) {
+        const float c0 = (COMPACT ? (float)xlj : dlf) - mu;
+        float V0 = 0.f, V1 = 0.f;
+        int xo3 = xr_off;
+        asm volatile("" : "+v"(xo3));
+        const int *xp3 = reinterpret_cast<const int *>(lds) + xo3;
+#pragma unroll
+        for (int m = 0; m < NTL; ++m) {
+            if (m < ntile) {
+                int4 p;
+                if (COMPACT) p = *reinterpret_cast<const int4 *>(xp3 + 16 * m);
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    float d0, d1;
+                    if (COMPACT) {
+                        d0 = c0 - (float)(r == 0 ? p.x : p.z);
+                        d1 = c0 - (float)(r == 0 ? p.y : p.w);
+                    } else {
+                        d0 = (float)(16 * m - r) + c0;
+                        d1 = (float)(16 * m - r - 1) + c0;
+                    }
+                    V0 = fmaf(acc[m][r] * d0, d0, V0);
+                    V1 = fmaf(acc[m][r + 1] * d1, d1, V1);
+                }
+            }
+        }
+        float Vl = V0 + V1;
+        Vl += __shfl_xor(Vl, 16);
+        Vl += __shfl_xor(Vl, 32);
+        var = (Vl + 0.000001f) / S;
+    }
+    mx_o = mx; S_o = S; mu_o = mu; var_o = var;
 }
 
 // KQ = number of K=4 channel steps when known at compile time (C <= 4*KQ), 0 = runtime loop.
@@ -87,31 +233,66 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int segs_per_row, int XT) {
+    int H, int W, int D, int segs_per_row, int XT, int allow_compact) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Layout lo = make_layout(C, NT, XT);
-    float *Rs = smem + lo.offR;    // [Cq][RP]   Rs[c][j] = R[c][xs - HALO + j]
-    float *Bi = smem + lo.offB;    // [RP]       0 where the right mask is on, else -1e30
+    float *Rs = smem + lo.offR;
+    float *BX = smem + lo.offBX;
+    int *XR = reinterpret_cast<int *>(BX);
+    int *RK = reinterpret_cast<int *>(smem + lo.offRK);
+    float *LM = smem + lo.offLM;
+    int *RKL = reinterpret_cast<int *>(LM);
+    int *XL = reinterpret_cast<int *>(smem + lo.offXL);
+    int *WT = reinterpret_cast<int *>(smem + lo.offWT);
     const int SW = lo.SW, HALO = lo.HALO, RP = lo.RP;
     const int kq_n = KQ ? KQ : lo.Cq / 4;
+    constexpr int KB = KQ ? KQ : 1;
 
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = blockIdx.x % segs_per_row, row = blockIdx.x / segs_per_row;
     const int b = row / H, y = row - b * H;
     const int xs = seg * SW;
+    const int nRw = HALO + SW;                       // staged right positions (multiple of 16)
     const size_t plane = (size_t)H * W;
     const float *lrow = ref + ((size_t)b * C * H + y) * W;
+    const float *rrow = tar + ((size_t)b * C * H + y) * W;
+    const float *trow = tmask + (size_t)row * W;
+    const float *mrow = rmask + (size_t)row * W;
+    const size_t rowpix = (size_t)row * W;
+
+    // ---------------- phase 1: masks -> LDS, flags kept in registers, block-wide counts ----------
+    const int p4 = tid * 4;                          // this thread's 4 positions (RP, SW <= 2048)
+    int fr = 0, fl = 0;                              // 4 right / left activity bits
     {
-        // stage R and the mask bias: every load of an 8-channel group is issued before the
-        // first LDS store (one HBM round trip per 8 channels instead of one per row)
-        const float *rrow = tar + ((size_t)b * C * H + y) * W;
-        const float *trow = tmask + (size_t)row * W;
-        const int nR = HALO + SW;
-        const bool al = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
-        const bool alm = (((uintptr_t)trow) & 15) == 0;
-        for (int j = threadIdx.x * 4; j < nR; j += THREADS * 4) {
-            const int x = xs - HALO + j;
+        const bool alm = (((uintptr_t)trow) & 15) == 0 && (((uintptr_t)mrow) & 15) == 0;
+        if (p4 < nRw) {
+            const int x = xs - HALO + p4;
             float4 tv = load4(trow, x, W, alm);
-            for (int c0 = 0; c0 < lo.Cq; c0 += 8) {       // Cq % 4 == 0
+            fr = (tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3);
+            float4 bv4;
+            bv4.x = (fr & 1) ? 0.f : NEG_BIG;
+            bv4.y = (fr & 2) ? 0.f : NEG_BIG;
+            bv4.z = (fr & 4) ? 0.f : NEG_BIG;
+            bv4.w = (fr & 8) ? 0.f : NEG_BIG;
+            *reinterpret_cast<float4 *>(BX + p4) = bv4;
+        }
+        if (p4 < SW) {
+            float4 mv = load4(mrow, xs + p4, W, alm);
+            fl = (mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3);
+            *reinterpret_cast<float4 *>(LM + p4) = mv;
+        }
+    }
+    {   // per-wave totals only: nothing of the scan stays live across the dense path
+        const int ir = wave_incl_scan(__popc(fr), lane), il = wave_incl_scan(__popc(fl), lane);
+        if (lane == 63) { WT[wave] = ir; WT[8 + wave] = il; }
+    }
+
+    // ---------------- phase 2: stage R (every load of an 8-channel group before its stores) ------
+    {
+        const bool al = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+        for (int j = tid * 4; j < nRw; j += THREADS * 4) {
+            const int x = xs - HALO + j;
+            for (int c0 = 0; c0 < lo.Cq; c0 += 8) {
                 float4 v[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
@@ -121,188 +302,226 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
                 for (int c = 0; c < 8; ++c)
                     if (c0 + c < lo.Cq) *reinterpret_cast<float4 *>(Rs + (c0 + c) * RP + j) = v[c];
             }
-            float4 bv4;
-            bv4.x = (x >= 0 && x < W && tv.x != 0.f) ? 0.f : NEG_BIG;
-            bv4.y = (x + 1 >= 0 && x + 1 < W && tv.y != 0.f) ? 0.f : NEG_BIG;
-            bv4.z = (x + 2 >= 0 && x + 2 < W && tv.z != 0.f) ? 0.f : NEG_BIG;
-            bv4.w = (x + 3 >= 0 && x + 3 < W && tv.w != 0.f) ? 0.f : NEG_BIG;
-            *reinterpret_cast<float4 *>(Bi + j) = bv4;
+        }
+        for (int c = tid; c < lo.Cq; c += THREADS) Rs[c * RP + RP - 1] = 0.f;    // zero column
+    }
+    __syncthreads();
+
+    int nR = 0, nL = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
+    const int validL = min(SW, W - xs);
+    const int validR = min(W, xs + SW) - max(0, xs - HALO);
+    // compact when fewer than 80 % of the candidate pairs are active (block-uniform)
+    const bool compact = allow_compact && ((long)nL * nR * 5 < (long)validL * validR * 4);
+
+    const int j = lane & 15, q = lane >> 4;
+
+    if (!compact) {
+        // =========================== DENSE path ===========================================
+        const int dl = j - 4 * q;                       // d = 16*m + dl - r
+        float bv[KB], bcur[KB];
+        float rm = 0.f;
+        auto fetch_left = [&](int xt, float (&dst)[KB]) {
+            const int x = xs + xt * 16 + j;
+            const bool ok = xt < XT && x < W;
+            if (KQ) {
+#pragma unroll
+                for (int s = 0; s < KQ; ++s)
+                    dst[s] = (ok && 4 * s + q < C) ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
+            }
+        };
+        fetch_left(wave, bv);
+        for (int xt = wave; xt < XT; xt += NWAVE) {
+            const int x0 = xs + xt * 16;
+            if (x0 >= W) break;
+            const int x = x0 + j;
+            const size_t pix = rowpix + x;
+            const bool inside = x < W;
+            rm = LM[xt * 16 + j];
+#pragma unroll
+            for (int s = 0; s < KB; ++s) bcur[s] = bv[s];
+            fetch_left(xt + NWAVE, bv);                 // prefetch the next tile's left operand
+            if (__ballot(rm != 0.f) == 0ull) {          // no active left pixel in this tile
+                if (inside && q == 0) {
+                    if (MODE != MODE_VAR) out[pix] = 0.f;
+                    if (MODE != MODE_MAT) var_out[pix] = 0.f;
+                    sum_sim[pix] = 0.f;
+                    max_cost[pix] = 0.f;
+                }
+                continue;
+            }
+            constexpr int nact = NT;                    // tiles left of the image read the zero /
+                                                        // -1e30 padding and come out as -1e30
+
+            // banded costs: the c-ordered fp32 fma chain of SM_kernel.cu:52-55 on the matrix
+            // cores, then + (0 | -1e30) for the right mask (SM_kernel.cu:48)
+            f32x4 acc[NT];
+            const float *ap = Rs + q * RP + (HALO + xt * 16) + j;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                if (m < nact) {
+                    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#if DECNET_ABLATE == 1 || DECNET_ABLATE == 3
+                    a4 = f32x4{ap[-16 * m], ap[(4 * RP) - 16 * m], bcur[0], bcur[KB - 1]};
+#else
+                    if (KQ) {
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[-16 * m], bcur[0],
+                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                        for (int s = 1; s < KQ; ++s)
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP - 16 * m], bcur[s], a4, 0, 0, 0);
+                    } else {
+                        const float *bp = lrow + (size_t)q * plane + x;   // generic C: L from L2/HBM
+                        for (int s = 0; s < kq_n; ++s) {
+                            const float lv = (inside && 4 * s + q < C) ? bp[(size_t)4 * s * plane] : 0.f;
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP - 16 * m], lv, a4, 0, 0, 0);
+                        }
+                    }
+#endif
+                    acc[m] = a4;
+                }
+            }
+#if DECNET_ABLATE == 2 || DECNET_ABLATE == 3
+            {
+#pragma unroll
+                for (int m = 0; m < NT; ++m) if (m < nact) asm volatile("" :: "v"(acc[m]));
+                if (inside && q == 0) { out[pix] = 0.f; var_out[pix] = 0.f; sum_sim[pix] = 0.f; max_cost[pix] = rm; }
+                continue;
+            }
+#endif
+            float mx, S, mu, var;
+            const float mu_in = (MODE == MODE_VAR && inside) ? disparity[pix] : 0.f;
+            softmax_passes<NT, MODE, false>(acc, nact, D, dl, smem, lo.offBX + (HALO + xt * 16) + 4 * q, 0, 0, mu_in, mx, S, mu, var);
+            if (inside && q == 0) {
+                const bool on = rm != 0.f;
+                if (MODE != MODE_VAR) out[pix] = on ? mu : 0.f;
+                if (MODE != MODE_MAT) var_out[pix] = on ? var : 0.f;
+                sum_sim[pix] = on ? S : 0.f;
+                max_cost[pix] = on ? mx : 0.f;
+            }
+        }
+        return;
+    }
+
+    // =============================== COMPACT path ==========================================
+    {
+        // the activity flags are re-read from BX / LM (cheaper than keeping them and the scan
+        // live across the dense path) before those arrays are reused for the compacted lists
+        int fr2 = 0, fl2 = 0;
+        if (p4 < nRw) {
+            const float4 t = *reinterpret_cast<const float4 *>(BX + p4);
+            fr2 = (t.x == 0.f) | ((t.y == 0.f) << 1) | ((t.z == 0.f) << 2) | ((t.w == 0.f) << 3);
+        }
+        if (p4 < SW) {
+            const float4 t = *reinterpret_cast<const float4 *>(LM + p4);
+            fl2 = (t.x != 0.f) | ((t.y != 0.f) << 1) | ((t.z != 0.f) << 2) | ((t.w != 0.f) << 3);
+        }
+        const int cr = __popc(fr2), cl = __popc(fl2);
+        const int ir = wave_incl_scan(cr, lane), il = wave_incl_scan(cl, lane);
+        int baseR = 0, baseL = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w)
+            if (w < wave) { baseR += WT[w]; baseL += WT[8 + w]; }
+        __syncthreads();                               // everyone is done reading WT / BX / LM
+        const int fr = fr2, fl = fl2;
+        int er = baseR + ir - cr, el = baseL + il - cl;     // exclusive counts at p4
+        if (p4 < nRw) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                RK[p4 + k] = er;
+                if (fr & (1 << k)) XR[er++] = p4 + k;
+            }
+        }
+        if (p4 < SW) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                RKL[p4 + k] = el;
+                if (fl & (1 << k)) XL[el++] = p4 + k;
+            }
+        }
+        if (tid == 0) { RK[nRw] = nR; RKL[SW] = nL; }
+        if (tid < 16 && nR + tid < RP) XR[nR + tid] = RP - 1;   // padded gathers hit the zero column
+    }
+    // span: a power-of-two number of pixels holding <= ~16 active left pixels ...
+    int S = 128;
+    while (S > 16 && (long)S * nL > 24L * validL) S >>= 1;
+    __syncthreads();
+    // ... whose disparity window holds at most 16*(NT+1) - 15 active right pixels everywhere
+    constexpr int NTC = NT + 1;
+    while (S > 16) {
+        int bad = 0;
+        for (int g = tid; g * S < SW; g += THREADS) {
+            const int jlo = max(0, g * S + HALO - (D - 1)), jhi = min(nRw - 1, g * S + HALO + S - 1);
+            if (RK[jhi + 1] - RK[jlo] > 16 * NTC - 15) bad = 1;
+        }
+        if (!__syncthreads_or(bad)) break;
+        S >>= 1;
+    }
+
+    // zero fill of the masked-off left pixels (functions/SpaMat.py:25-27 semantics)
+    for (int p = tid; p < validL; p += THREADS) {
+        if (RKL[p + 1] == RKL[p]) {
+            const size_t pix = rowpix + xs + p;
+            if (MODE != MODE_VAR) out[pix] = 0.f;
+            if (MODE != MODE_MAT) var_out[pix] = 0.f;
+            sum_sim[pix] = 0.f;
+            max_cost[pix] = 0.f;
         }
     }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int dl = j - 4 * q;                       // d = 16*m + dl - r
-    const float dlf = (float)dl;
-    const float bb = q == 0 ? 1.f : 0.f;            // B operand of the mask K-step
-
-    // left operand + left mask of this wave's first tile (HBM -> registers)
-    float bv[KQ ? KQ : 1];
-    float rm = 0.f;
-    auto fetch_left = [&](int xt, float (&dst)[KQ ? KQ : 1], float &m) {
-        const int x = xs + xt * 16 + j;
-        const bool ok = xt < XT && x < W;
-        m = ok ? rmask[(size_t)row * W + x] : 0.f;
-        if (KQ) {
+    const int ngroups = (SW + S - 1) / S;
+    for (int g = wave; g < ngroups; g += NWAVE) {
+        const int gx = g * S;
+        const int e0 = RKL[gx], e1 = RKL[min(gx + S, SW)];
+        if (e1 == e0) continue;
+        const int jlo = max(0, gx + HALO - (D - 1)), jhi = min(nRw - 1, gx + HALO + S - 1);
+        const int r_lo = RK[jlo], r_hi = RK[jhi + 1];
+        const int t0 = r_lo >> 4;
+        const int ntile = r_hi > r_lo ? ((r_hi - 1) >> 4) - t0 + 1 : 0;      // <= NTC
+        for (int e = e0; e < e1; e += 16) {
+            const bool act = e + j < e1;
+            const int xl = XL[act ? e + j : e1 - 1];           // local left position
+            const int x = xs + xl;
+            const size_t pix = rowpix + x;
+            float bcur[KB];
+            if (KQ) {
 #pragma unroll
-            for (int s = 0; s < KQ; ++s)
-                dst[s] = (ok && 4 * s + q < C) ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
-        }
-    };
-    fetch_left(wave, bv, rm);
-    __syncthreads();
-
-    for (int xt = wave; xt < XT; xt += THREADS / 64) {
-        const int x0 = xs + xt * 16;
-        if (x0 >= W) break;
-        const int x = x0 + j;
-        const size_t pix = (size_t)row * W + x;
-        const bool inside = x < W;
-        const float rm_cur = rm;
-        float bcur[KQ ? KQ : 1];
-#pragma unroll
-        for (int s = 0; s < (KQ ? KQ : 1); ++s) bcur[s] = bv[s];
-        fetch_left(xt + THREADS / 64, bv, rm);      // prefetch the next tile's left operand
-        if (__ballot(rm_cur != 0.f) == 0ull) {      // no active left pixel in this tile
-            if (inside && q == 0) {
-                if (MODE != MODE_VAR) out[pix] = 0.f;
-                if (MODE != MODE_MAT) var_out[pix] = 0.f;
-                sum_sim[pix] = 0.f;
-                max_cost[pix] = 0.f;
+                for (int s = 0; s < KQ; ++s)
+                    bcur[s] = (act && 4 * s + q < C) ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
             }
-            continue;
-        }
-
-        // ---- banded costs on the matrix cores: the c-ordered fp32 fma chain of
-        //      SM_kernel.cu:52-55, then + (0 | -1e30) for the right mask (:48).  Tiles that lie
-        //      left of the image read the zero / -1e30 padding and come out as -1e30. -------
-        f32x4 acc[NT];
-        const float *ap = Rs + q * RP + (HALO + xt * 16) + j;
-        const float *bi = Bi + (HALO + xt * 16) + j;
-#if DECNET_ABLATE == 1 || DECNET_ABLATE == 3      // timing-only build: no matrix-core work
-        if (KQ) {
+            f32x4 acc[NTC];
+            const int *xa = XR + 16 * t0 + j;                  // A-operand gather index
 #pragma unroll
-            for (int m = 0; m < NT; ++m) {
-                const float ab = q == 0 ? bi[-16 * m] : 0.f;
-                acc[m] = f32x4{ap[-16 * m], ap[4 * RP - 16 * m], bcur[0] + ab, bcur[KQ - 1]};
-            }
-        } else
-#endif
-        if (KQ) {
+            for (int m = 0; m < NTC; ++m) {
+                if (m < ntile) {
+                    const float *ap = Rs + q * RP + xa[16 * m];
+                    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (KQ) {
 #pragma unroll
-            for (int m = 0; m < NT; ++m) {
-                f32x4 a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[-16 * m], bcur[0],
-                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-                for (int s = 1; s < KQ; ++s)
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP - 16 * m], bcur[s], a4, 0, 0, 0);
-                const float ab = q == 0 ? bi[-16 * m] : 0.f;
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab, bb, a4, 0, 0, 0);
-            }
-        } else {
-            const float *bp = lrow + (size_t)q * plane + x;     // generic C: left operand from L2/HBM
-#pragma unroll
-            for (int m = 0; m < NT; ++m) {
-                f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < kq_n; ++s) {
-                    const float lv = (inside && 4 * s + q < C) ? bp[(size_t)4 * s * plane] : 0.f;
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP - 16 * m], lv, a4, 0, 0, 0);
-                }
-                const float ab = q == 0 ? bi[-16 * m] : 0.f;
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab, bb, a4, 0, 0, 0);
-            }
-        }
-
-#if DECNET_ABLATE == 2 || DECNET_ABLATE == 3      // timing-only build: no softmax passes
-        {
-            float keep = 0.f;
-#pragma unroll
-            for (int m = 0; m < NT; ++m) asm volatile("" :: "v"(acc[m]));
-            if (inside && q == 0) { out[pix] = keep; var_out[pix] = keep; sum_sim[pix] = keep; max_cost[pix] = rm_cur; }
-            continue;
-        }
-#endif
-        // ---- pass 1: disparity range 0 <= d < min(D, x+1) (SM_kernel.cu:42,46; only the
-        //      diagonal and the last tiles can violate it; x' >= 0 is covered by the padding),
-        //      then max_cost = max(1e-6, max_d cost_d)  (SM_kernel.cu:45-59) -----------------
-        int dlv = dl;
-        asm volatile("" : "+v"(dlv));   // opaque per tile: otherwise LICM hoists every range
-                                        // compare out of the tile loop and spills their masks
-        float mx0 = 0.000001f, mx1 = 0.000001f;
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            if (m == 0 || 16 * m + 15 >= D) {
-                asm volatile("" ::: "memory");      // keep a real scalar branch (no if-conversion)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = 16 * m + dlv - r;
-                    acc[m][r] = (unsigned)d >= (unsigned)D ? NEG_BIG : acc[m][r];
+                        for (int s = 0; s < KQ; ++s)
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP], bcur[s], a4, 0, 0, 0);
+                    } else {
+                        const float *bp = lrow + (size_t)q * plane + x;
+                        for (int s = 0; s < kq_n; ++s) {
+                            const float lv = (act && 4 * s + q < C) ? bp[(size_t)4 * s * plane] : 0.f;
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP], lv, a4, 0, 0, 0);
+                        }
+                    }
+                    acc[m] = a4;
                 }
             }
-            mx0 = fmaxf(fmaxf(mx0, acc[m][0]), acc[m][1]);
-            mx1 = fmaxf(fmaxf(mx1, acc[m][2]), acc[m][3]);
-        }
-        float mx = fmaxf(mx0, mx1);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-
-        // ---- pass 2: e = exp(cost - max); S = sum e; T = sum e*d  (SM_kernel.cu:100-122) ---
-        float S0 = 0.f, S1 = 0.f, T0 = 0.f, T1 = 0.f;
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                float e0 = fast_exp2((acc[m][r] - mx) * LOG2E);
-                float e1 = fast_exp2((acc[m][r + 1] - mx) * LOG2E);
-                acc[m][r] = e0;
-                acc[m][r + 1] = e1;
-                S0 += e0;
-                S1 += e1;
-                if (MODE != MODE_VAR) {
-                    T0 = fmaf(e0, (float)(16 * m - r), T0);
-                    T1 = fmaf(e1, (float)(16 * m - r - 1), T1);
-                }
+            float mx, Ssum, mu, var;
+            const float mu_in = (MODE == MODE_VAR && act) ? disparity[pix] : 0.f;
+            // d = (xl + HALO) - XR[...]: both in staged-row coordinates
+            softmax_passes<NTC, MODE, true>(acc, ntile, D, 0, smem, 0, lo.offBX + 16 * t0 + 4 * q, xl + HALO, mu_in,
+                                            mx, Ssum, mu, var);
+            if (act && q == 0) {
+                if (MODE != MODE_VAR) out[pix] = mu;
+                if (MODE != MODE_MAT) var_out[pix] = var;
+                sum_sim[pix] = Ssum;
+                max_cost[pix] = mx;
             }
-        }
-        float Sl = S0 + S1;
-        float Tl = fmaf(dlf, Sl, T0 + T1);           // d = (16m - r) + dl
-        Sl += __shfl_xor(Sl, 16);
-        Sl += __shfl_xor(Sl, 32);
-        const float S = Sl + 0.000001f;
-        float mu;
-        if (MODE == MODE_VAR) {
-            mu = inside ? disparity[pix] : 0.f;
-        } else {
-            Tl += __shfl_xor(Tl, 16);
-            Tl += __shfl_xor(Tl, 32);
-            mu = (Tl + 0.000001f) / S;
-        }
-
-        // ---- pass 3: V = sum e*(d-mu)^2  (SV_kernel.cu:100-121) ---------------------------
-        float var = 0.f;
-        if (MODE != MODE_MAT) {
-            const float c0 = dlf - mu;
-            float V0 = 0.f, V1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < NT; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    float d0 = (float)(16 * m - r) + c0, d1 = (float)(16 * m - r - 1) + c0;
-                    V0 = fmaf(acc[m][r] * d0, d0, V0);
-                    V1 = fmaf(acc[m][r + 1] * d1, d1, V1);
-                }
-            }
-            float Vl = V0 + V1;
-            Vl += __shfl_xor(Vl, 16);
-            Vl += __shfl_xor(Vl, 32);
-            var = (Vl + 0.000001f) / S;
-        }
-        if (inside && q == 0) {
-            const bool on = rm_cur != 0.f;
-            if (MODE != MODE_VAR) out[pix] = on ? mu : 0.f;
-            if (MODE != MODE_MAT) var_out[pix] = on ? var : 0.f;
-            sum_sim[pix] = on ? S : 0.f;
-            max_cost[pix] = on ? mx : 0.f;
         }
     }
 }
@@ -310,27 +529,28 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
 template <int NT, int KQ>
 int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
-              int B, int C, int H, int W, int D, hipStream_t stream) {
+              int B, int C, int H, int W, int D, int allow_compact, hipStream_t stream) {
     const int xt_row = ceil_div(W, 16);
     auto bytes = [&](int xt) { return (size_t)4 * make_layout(C, NT, xt).total; };
     // whole row per workgroup when two workgroups (16 waves) still fit a CU's LDS; otherwise
-    // equal segments that do; otherwise whatever fits once.
+    // equal segments that do; otherwise whatever fits once.  Segments hold <= 64 tiles so that
+    // one thread covers 4 pixels of the mask scan.
     const size_t budget2 = (DECNET_LDS_BYTES - 2048) / 2, budget1 = DECNET_LDS_BYTES - 1024;
-    int XT = xt_row;
+    int XT = xt_row > 64 ? ceil_div(xt_row, ceil_div(xt_row, 64)) : xt_row;
     if (bytes(XT) > budget2) {
-        int segs = 2;
+        int segs = ceil_div(xt_row, XT) + 1;
         while (segs < xt_row && bytes(ceil_div(xt_row, segs)) > budget2) ++segs;
-        XT = ceil_div(xt_row, segs);
-        if (bytes(XT) > budget2) {
-            XT = xt_row;
+        int xt2 = ceil_div(xt_row, segs);
+        if (bytes(xt2) <= budget2) XT = xt2;
+        else {
             while (XT > 1 && bytes(XT) > budget1) --XT;
-            if (bytes(XT) > budget1) return DECNET_ERR_UNSUPPORTED;
         }
     }
     XT = (XT + 1) & ~1;                               // segment starts stay 32-float aligned
-    const int segs = ceil_div(xt_row, XT);
+    if (XT > 64) XT = 64;
     const size_t lds = bytes(XT);
-    if (lds > budget1) return DECNET_ERR_UNSUPPORTED;
+    if (lds > budget1 || make_layout(C, NT, XT).RP > 2048) return DECNET_ERR_UNSUPPORTED;
+    const int segs = ceil_div(xt_row, XT);
     dim3 grid((unsigned)((size_t)B * H * segs)), block(THREADS);
 #define LAUNCH(M)                                                                                  \
     do {                                                                                           \
@@ -340,7 +560,8 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
             if (e != hipSuccess) return (int)e;                                                    \
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ>), grid, block, lds, stream, ref, tar, rmask, \
-                           tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT); \
+                           tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT, \
+                           allow_compact);                                                         \
     } while (0)
     if (mode == MODE_MAT) LAUNCH(MODE_MAT);
     else if (mode == MODE_VAR) LAUNCH(MODE_VAR);
@@ -352,10 +573,10 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
 template <int NT>
 int launch_kq(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
-              int B, int C, int H, int W, int D, hipStream_t stream) {
+              int B, int C, int H, int W, int D, int allow_compact, hipStream_t stream) {
 #define GO(K)                                                                                      \
     return launch_nt<NT, K>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,        \
-                            max_cost, B, C, H, W, D, stream)
+                            max_cost, B, C, H, W, D, allow_compact, stream)
     if (C <= 8 && C > 4) GO(2);        // stage 3 of the shipped network (C = 8)
     if (C <= 24 && C > 20) GO(6);      // stage 2 (C = 24)
     GO(0);                             // anything else, incl. stage 1 (C = 72): runtime K loop,
@@ -366,24 +587,23 @@ int launch_kq(int mode, const float *ref, const float *tar, const float *rmask, 
 }  // namespace
 
 // mode: 0 SpaMat, 1 SpaVar, 2 fused.  Returns DECNET_ERR_UNSUPPORTED when the band needs more
-// than 20 tiles (max_disp > 305) or a tile does not fit LDS; the dispatcher in capi.hip then
-// uses the row-tile kernel.
+// than 18 tiles (max_disp > 272) or a tile does not fit LDS; the dispatcher in capi.hip then
+// uses the row-tile kernel.  allow_compact = 0 pins the dense path (A/B benchmarks, tests).
 int decnet_mfma_forward(int mode, const float *ref, const float *tar, const float *rmask,
                         const float *tmask, const float *disparity, float *out, float *var_out,
                         float *sum_sim, float *max_cost, int B, int C, int H, int W, int max_disp,
-                        hipStream_t stream) {
+                        int allow_compact, hipStream_t stream) {
     const int D = max_disp;
     const int need = D <= 1 ? 1 : (D - 1 + 15) / 16 + 1;
 #define GO(N)                                                                                     \
     return launch_kq<N>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, \
-                        B, C, H, W, D, stream)
+                        B, C, H, W, D, allow_compact, stream)
     if (need <= 3) GO(3);       // D <= 32   (stage 1: 24, 30)
     if (need <= 6) GO(6);       // D <= 80   (stage 2: 72)
     if (need <= 8) GO(8);       // D <= 112  (stage 2 at max_disp 270: 90)
     if (need <= 11) GO(11);     // D <= 160
     if (need <= 15) GO(15);     // D <= 224  (stage 3: 216)
     if (need <= 18) GO(18);     // D <= 272  (stage 3 at max_disp 270)
-    if (need <= 20) GO(20);     // D <= 304
 #undef GO
     return DECNET_ERR_UNSUPPORTED;
 }

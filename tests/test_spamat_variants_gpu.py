@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("variant", ["rowtile", "mfma"])
+@pytest.mark.parametrize("variant", ["rowtile", "mfma", "mfma_dense"])
 def test_forward_suite_with_pinned_variant(variant):
     env = dict(os.environ, DECNET_SPAMAT_KERNEL=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spamat_gpu.py"),
