@@ -199,6 +199,14 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        # HBM-side traffic per launch comes from a separate rocprofv3 --pmc pass (counters cannot be
+        # read from inside the process); profiles/traffic.json records the command and corrections.
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f)
+        except (OSError, ValueError):
+            pass
         ms_step = 1e3 * elapsed / args.steps
         pairs = world * B * args.steps
         # --- dominant kernel: conv3d_k3_igemm (7 launches inside stage 0), live events -------
@@ -244,11 +252,13 @@ def main():
                        "parallelism": "dp%d (pairs sharded, all_gather of disparity maps)" % world},
             "roofline": {"bound": "mfma", "achieved": conv_flop / conv_ms / 1e9, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": conv_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
-                         "traffic": None, "kernel": "conv3d_k3_igemm (216->216, 3^3, M=%d)" % M,
+                         "traffic": traffic.get("conv3d_k3_igemm", {}).get("total_bytes"),
+                         "kernel": "conv3d_k3_igemm (216->216, 3^3, M=%d)" % M,
                          "ms": conv_ms, "flop_per_launch": conv_flop, "stage0_ms_in_step": s0_ms},
             "roofline_costvol": {"bound": "hbm", "achieved": s3_bytes / s3_ms / 1e6, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": s3_bytes / s3_ms / 1e6 / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "spamat fused fwd, stage 3",
+                                 "traffic": traffic.get("spamat_fused_stage3", {}).get("total_bytes"),
+                                 "kernel": "spamat fused fwd, stage 3",
                                  "mask_density": args.mask_density, "ms": s3_ms,
                                  "bytes_per_launch": s3_bytes},
         }
