@@ -306,6 +306,9 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
         for (int c = tid; c < lo.Cq; c += THREADS) Rs[c * RP + RP - 1] = 0.f;    // zero column
     }
     __syncthreads();
+#if DECNET_ABLATE == 5      // timing-only: mask + R staging only
+    return;
+#endif
 
     int nR = 0, nL = 0;
 #pragma unroll
@@ -470,6 +473,9 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
         }
     }
 
+#if DECNET_ABLATE == 4      // timing-only: staging + compaction + zero fill, no matching
+    return;
+#endif
     const int ngroups = (SW + S - 1) / S;
     for (int g = wave; g < ngroups; g += NWAVE) {
         const int gx = g * S;

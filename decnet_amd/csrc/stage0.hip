@@ -34,37 +34,54 @@ constexpr int B_PITCH = 240;   // == 16 (mod 32): rows kq, kq+1 land on opposite
 // Coordinates are formed with the same fp32 operation sequence as the reference + torch:
 //   cx = (x-d) / ((W-1)/2) - 1      (submodule.py:497-498)
 //   ix = ((cx + 1) * W - 1) / 2     (grid_sample, align_corners=False)
-__global__ void costvol_cor_ndhwc(const float *__restrict__ left, const float *__restrict__ right,
-                                  float *__restrict__ cost, int B, int C, int H, int W, int D,
-                                  size_t total) {
+// One workgroup per (b, y): the left row and the two right rows the bilinear taps touch are read
+// once, x-contiguous (NCHW), into LDS; every (d, x, c) product is then formed from LDS and
+// written c-contiguous (channels-last), so both HBM sides are coalesced.
+__global__ __launch_bounds__(256) void costvol_cor_ndhwc(const float *__restrict__ left,
+                                                         const float *__restrict__ right,
+                                                         float *__restrict__ cost, int C, int H,
+                                                         int W, int D) {
 #pragma clang fp contract(off)
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    int c = (int)(idx % C);
-    size_t p = idx / C;
-    int x = (int)(p % W); p /= W;
-    int y = (int)(p % H); p /= H;
-    int d = (int)(p % D);
-    int b = (int)(p / D);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int WP = W | 1;                      // odd pitch: column reads across c are conflict-free
+    float *Ls = smem;                          // [C][WP]
+    float *R0 = Ls + C * WP;                   // [C][WP]   row y0 (zeros if outside)
+    float *R1 = R0 + C * WP;                   // [C][WP]   row y0 + 1
+    const int b = blockIdx.x / H, y = blockIdx.x - b * H;
+    const float cy = (float)y / ((float)(H - 1.0) / 2.0f) - 1.0f;
+    const float iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float fy = floorf(iy);
+    const int y0 = (int)fy, y1 = y0 + 1;
+    const float wy1 = iy - fy, wy0 = 1.0f - wy1;
     const size_t plane = (size_t)H * W;
-    const float *Lp = left + ((size_t)b * C + c) * plane;
-    const float *Rp = right + ((size_t)b * C + c) * plane;
-    float l = x >= d ? Lp[(size_t)y * W + x] : 0.f;          // submodule.py:506-508
-    float cx = (float)(x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
-    float cy = (float)y / ((float)(H - 1.0) / 2.0f) - 1.0f;
-    float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f;
-    float iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
-    float fx = floorf(ix), fy = floorf(iy);
-    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-    float wx1 = ix - fx, wx0 = 1.0f - wx1, wy1 = iy - fy, wy0 = 1.0f - wy1;
-    bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
-    bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
-    float r = 0.f;
-    if (vy0 && vx0) r += Rp[(size_t)y0 * W + x0] * (wx0 * wy0);
-    if (vy0 && vx1) r += Rp[(size_t)y0 * W + x1] * (wx1 * wy0);
-    if (vy1 && vx0) r += Rp[(size_t)y1 * W + x0] * (wx0 * wy1);
-    if (vy1 && vx1) r += Rp[(size_t)y1 * W + x1] * (wx1 * wy1);
-    cost[idx] = l * r;                                       // submodule.py:521
+    const float *Lb = left + (size_t)b * C * plane, *Rb = right + (size_t)b * C * plane;
+    for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
+        int c = i / W, x = i - c * W;
+        Ls[c * WP + x] = Lb[c * plane + (size_t)y * W + x];
+        R0[c * WP + x] = (y0 >= 0 && y0 < H) ? Rb[c * plane + (size_t)y0 * W + x] : 0.f;
+        R1[c * WP + x] = (y1 >= 0 && y1 < H) ? Rb[c * plane + (size_t)y1 * W + x] : 0.f;
+    }
+    __syncthreads();
+    const int n = D * W * C;
+    float *out = cost + (size_t)b * D * plane * C + (size_t)y * W * C;     // + d*plane*C + x*C + c
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int c = i % C, t = i / C;
+        int x = t % W, d = t / W;
+        float l = x >= d ? Ls[c * WP + x] : 0.f;                  // submodule.py:506-508
+        float cx = (float)(x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
+        float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f;
+        float fx = floorf(ix);
+        int x0 = (int)fx, x1 = x0 + 1;
+        float wx1 = ix - fx, wx0 = 1.0f - wx1;
+        bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+        bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+        float r = 0.f;                                            // same tap order as grid_sample
+        if (vy0 && vx0) r += R0[c * WP + x0] * (wx0 * wy0);
+        if (vy0 && vx1) r += R0[c * WP + x1] * (wx1 * wy0);
+        if (vy1 && vx0) r += R1[c * WP + x0] * (wx0 * wy1);
+        if (vy1 && vx1) r += R1[c * WP + x1] * (wx1 * wy1);
+        out[(size_t)d * plane * C + (size_t)x * C + c] = l * r;   // submodule.py:521
+    }
 }
 
 // ----------------------------------- weight repack -------------------------------------
@@ -583,10 +600,18 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
                            int W, int D, void *stream) {
     if (!left || !right || !cost) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || C < 1 || H < 2 || W < 2 || D < 1) return DECNET_ERR_BAD_SHAPE;
-    size_t total = (size_t)B * D * H * W * C;
-    if (total >= ((size_t)1 << 40)) return DECNET_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, left, right, cost, B, C, H, W, D, total);
+    if ((double)B * D * H * W * C >= 1099511627776.0 || (double)D * W * C >= 2147483648.0 ||
+        (double)B * H >= 2147483648.0)
+        return DECNET_ERR_BAD_SHAPE;
+    size_t lds = (size_t)3 * C * (W | 1) * 4;
+    if (lds > DECNET_LDS_BYTES - 1024) return DECNET_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)costvol_cor_ndhwc,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H)), dim3(256), lds, (hipStream_t)stream,
+                       left, right, cost, C, H, W, D);
     return decnet_launch_status();
 }
 
