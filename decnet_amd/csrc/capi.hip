@@ -19,8 +19,42 @@ int decnet_mfma_forward(int mode, const float *ref, const float *tar, const floa
                         float *sum_sim, float *max_cost, int B, int C, int H, int W, int max_disp,
                         int allow_compact, hipStream_t stream);
 
+// kernels in spamat_bwd_mfma.hip
+int decnet_mfma_backward(int var, const float *ref, const float *tar, const float *rmask,
+                         const float *tmask, const float *disparity, const float *out,
+                         const float *sum_sim, const float *max_cost, const float *grad_out,
+                         float *grad_ref, float *grad_tar, float *grad_disp, int B, int C, int H,
+                         int W, int max_disp, hipStream_t stream);
+
 #include <stdlib.h>
 #include <string.h>
+
+static int spamat_pinned() {       // DECNET_SPAMAT_KERNEL, read once
+    static const int pinned = [] {
+        const char *e = getenv("DECNET_SPAMAT_KERNEL");
+        if (!e) return 0;
+        return !strcmp(e, "rowtile") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "mfma_dense") ? 3 : 0;
+    }();
+    return pinned;
+}
+
+// Backward dispatch: matrix-core kernels, row-tile kernels for what they do not cover.
+static int backward_dispatch(int var, const float *ref, const float *tar, const float *rmask,
+                             const float *tmask, const float *disparity, const float *out,
+                             const float *sum_sim, const float *max_cost, const float *grad_out,
+                             float *grad_ref, float *grad_tar, float *grad_disp, int B, int C, int H,
+                             int W, int max_disp, hipStream_t stream) {
+    const int pinned = spamat_pinned();
+    if (pinned != 1) {
+        int rc = decnet_mfma_backward(var, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
+                                      grad_out, grad_ref, grad_tar, grad_disp, B, C, H, W, max_disp,
+                                      stream);
+        if (rc != DECNET_ERR_UNSUPPORTED || pinned >= 2) return rc;
+    }
+    return decnet_rowtile_backward(var, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
+                                   grad_out, grad_ref, grad_tar, grad_disp, B, C, H, W, max_disp,
+                                   stream);
+}
 
 // Forward dispatch: the MFMA band kernel; the row-tile kernel covers what it cannot
 // (band wider than 18 tiles, LDS overflow).  DECNET_SPAMAT_KERNEL=rowtile|mfma|mfma_dense pins
@@ -30,11 +64,7 @@ static int forward_dispatch(int mode, const float *ref, const float *tar, const 
                             const float *tmask, const float *disparity, float *out, float *var_out,
                             float *sum_sim, float *max_cost, int B, int C, int H, int W,
                             int max_disp, hipStream_t stream) {
-    static const int pinned = [] {
-        const char *e = getenv("DECNET_SPAMAT_KERNEL");
-        if (!e) return 0;
-        return !strcmp(e, "rowtile") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "mfma_dense") ? 3 : 0;
-    }();
+    const int pinned = spamat_pinned();
     if (pinned != 1) {
         int rc = decnet_mfma_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
                                      max_cost, B, C, H, W, max_disp, pinned != 3, stream);
@@ -92,7 +122,7 @@ int decnet_spamat_backward(const float *ref, const float *tar, const float *ref_
                        grad_output, grad_ref, grad_tar};
     int rc = decnet_check_spamat_args(p, 10, B, C, H, W, max_disp);
     if (rc) return rc;
-    return decnet_rowtile_backward(0, ref, tar, ref_mask, tar_mask, nullptr, output,
+    return backward_dispatch(0, ref, tar, ref_mask, tar_mask, nullptr, output,
                                    sum_similarities, max_cost, grad_output, grad_ref, grad_tar,
                                    nullptr, B, C, H, W, max_disp, (hipStream_t)stream);
 }
@@ -107,7 +137,7 @@ int decnet_spavar_backward(const float *ref, const float *tar, const float *ref_
                        grad_output, grad_ref, grad_tar, grad_disparity};
     int rc = decnet_check_spamat_args(p, 12, B, C, H, W, max_disp);
     if (rc) return rc;
-    return decnet_rowtile_backward(1, ref, tar, ref_mask, tar_mask, disparity, output,
+    return backward_dispatch(1, ref, tar, ref_mask, tar_mask, disparity, output,
                                    sum_similarities, max_cost, grad_output, grad_ref, grad_tar,
                                    grad_disparity, B, C, H, W, max_disp, (hipStream_t)stream);
 }

@@ -1,0 +1,351 @@
+// decnet_amd/csrc/spamat_bwd_mfma.hip -- SpaMat / SpaVar backward on the matrix cores (gfx950).
+//
+// Replaces sparse_matching_ref_backward / sparse_matching_tar_backward (SM_kernel.cu:143-195,
+// 300-355) and sparse_var_{ref,tar,dis}_backward (SV_kernel.cu:142-325).  The reference runs one
+// thread per (b,c,y,x) and recomputes the whole C-channel dot product for every disparity in
+// every one of those C threads (O(C^2) per candidate).  Here a candidate's cost
+// and softmax weight are formed ONCE (cost tile by v_mfma_f32_16x16x4_f32, same c-ordered fp32
+// fma chain as the forward), and the weighted sum over disparities
+//     gL[c][x]  = g/S * sum_d  w(x,d)   * R[c][x-d]          w = e*(d-out)   (SpaMat)
+//     gR[c][x'] =       sum_d  w(x'+d,d)* L[c][x'+d] * g/S   w = e*((d-mu)^2-out)  (SpaVar)
+// is a second small matrix product contracted over the band -- also on the matrix cores, with the
+// weight tile used as an MFMA operand straight from the accumulator registers (step r of the
+// K loop takes accumulator register r: lane quad q supplies row 4q+r, so no transpose and no
+// LDS round trip).  The max of the forward is an input (max_cost), so no cost is ever stored:
+// each 16x16 tile is cost -> weight -> contraction and then dropped.
+//
+// SIDE 0 ("ref"): lanes own LEFT pixels, the staged "other" row is R with a left halo.
+// SIDE 1 ("tar"): lanes own RIGHT pixels, the staged "other" row is L with a right halo, and the
+//                 per-left-pixel scalars (max, out, g/S, mu, mask) are rows of the tile: LDS planes.
+// LDS: Os[Cq][OP] (OP == 4 mod 64: the contraction reads 4 consecutive pixels of one channel per
+//      lane with ds_read_b128, 16 channels x 4 quads conflict-free) | planes[NPL][OW].
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int THREADS = 512, NWAVE = THREADS / 64;
+
+__device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, int W, bool aligned) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aligned && x >= 0 && x + 3 < W) {
+        v = *reinterpret_cast<const float4 *>(row + x);
+    } else {
+        if (x >= 0 && x < W) v.x = row[x];
+        if (x + 1 >= 0 && x + 1 < W) v.y = row[x + 1];
+        if (x + 2 >= 0 && x + 2 < W) v.z = row[x + 2];
+        if (x + 3 >= 0 && x + 3 < W) v.w = row[x + 3];
+    }
+    return v;
+}
+
+struct BLayout {
+    int SW, HALO, OW, OP, Cq, offP, total;
+};
+__host__ __device__ inline BLayout make_blayout(int C, int NT, int XT, int npl) {
+    BLayout l;
+    l.SW = XT * 16;
+    l.HALO = (NT - 1) * 16;
+    l.OW = l.HALO + l.SW;                       // staged other-side pixels (multiple of 16)
+    l.OP = ((l.OW + 63) & ~63) + 4;
+    l.Cq = (C + 3) & ~3;
+    l.offP = l.Cq * l.OP;
+    l.total = l.offP + npl * l.OW;
+    return l;
+}
+
+// planes: 0 bias (0 / -1e30 of the other side's mask); SIDE 1 adds 1 -max*log2e, 2 out, 3 g/S, 4 mu
+template <int NT, bool VAR, int KQ, int SIDE>
+__global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity,
+    const float *__restrict__ out, const float *__restrict__ sum_sim,
+    const float *__restrict__ max_cost, const float *__restrict__ grad_out,
+    float *__restrict__ grad_own, float *__restrict__ grad_disp, int C, int H, int W, int D,
+    int segs_per_row, int XT) {
+    constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
+    constexpr int NCB = (4 * KQ + 15) / 16;          // 16-channel blocks of the contraction
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const BLayout lo = make_blayout(C, NT, XT, NPL);
+    float *Os = smem;
+    float *PL = smem + lo.offP;
+    const int SW = lo.SW, HALO = lo.HALO, OW = lo.OW, OP = lo.OP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = blockIdx.x % segs_per_row, row = blockIdx.x / segs_per_row;
+    const int b = row / H, y = row - b * H;
+    const int xs = seg * SW;
+    const int xo0 = SIDE == 0 ? xs - HALO : xs;      // image x of staged column 0
+    const size_t plane = (size_t)H * W;
+    const size_t rowpix = (size_t)row * W;
+    const float *own_row = (SIDE == 0 ? ref : tar) + ((size_t)b * C * H + y) * W;
+    const float *oth_row = (SIDE == 0 ? tar : ref) + ((size_t)b * C * H + y) * W;
+    const float *oth_mask = (SIDE == 0 ? tmask : rmask) + rowpix;
+
+    // ---- stage the other side's features and per-pixel planes ----------------------------------
+    {
+        const bool al = ((((uintptr_t)oth_row) | ((uintptr_t)(plane * 4))) & 15) == 0;
+        const bool alp = (rowpix & 3) == 0 && ((((uintptr_t)oth_mask) | ((uintptr_t)out) |
+                                                ((uintptr_t)sum_sim) | ((uintptr_t)max_cost) |
+                                                ((uintptr_t)grad_out)) & 15) == 0;
+        for (int j = tid * 4; j < OW; j += THREADS * 4) {
+            const int x = xo0 + j;
+            for (int c0 = 0; c0 < lo.Cq; c0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    v[c] = c0 + c < C ? load4(oth_row + (size_t)(c0 + c) * plane, x, W, al)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c0 + c < lo.Cq) *reinterpret_cast<float4 *>(Os + (c0 + c) * OP + j) = v[c];
+            }
+            const float4 mk = load4(oth_mask, x, W, alp);
+            const bool on[4] = {x >= 0 && x < W && mk.x != 0.f, x + 1 >= 0 && x + 1 < W && mk.y != 0.f,
+                                x + 2 >= 0 && x + 2 < W && mk.z != 0.f, x + 3 >= 0 && x + 3 < W && mk.w != 0.f};
+            float4 bz = make_float4(on[0] ? 0.f : NEG_BIG, on[1] ? 0.f : NEG_BIG, on[2] ? 0.f : NEG_BIG,
+                                    on[3] ? 0.f : NEG_BIG);
+            *reinterpret_cast<float4 *>(PL + j) = bz;
+            if (SIDE == 1) {
+                const float4 mx = load4(max_cost + rowpix, x, W, alp);
+                const float4 oo = load4(out + rowpix, x, W, alp);
+                const float4 gg = load4(grad_out + rowpix, x, W, alp);
+                const float4 ss = load4(sum_sim + rowpix, x, W, alp);
+                *reinterpret_cast<float4 *>(PL + OW + j) =
+                    make_float4(-mx.x * LOG2E, -mx.y * LOG2E, -mx.z * LOG2E, -mx.w * LOG2E);
+                *reinterpret_cast<float4 *>(PL + 2 * OW + j) = oo;
+                *reinterpret_cast<float4 *>(PL + 3 * OW + j) =          // g/S, 0 where the left mask is off
+                    make_float4(on[0] ? gg.x / ss.x : 0.f, on[1] ? gg.y / ss.y : 0.f,
+                                on[2] ? gg.z / ss.z : 0.f, on[3] ? gg.w / ss.w : 0.f);
+                if (VAR) *reinterpret_cast<float4 *>(PL + 4 * OW + j) = load4(disparity + rowpix, x, W, alp);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int j = lane & 15, q = lane >> 4;
+    const int cj = j < lo.Cq ? j : lo.Cq - 1;        // channel this lane supplies to the contraction
+    float bv[KQ], bcur[KQ];
+    auto fetch_own = [&](int xt, float (&dst)[KQ]) {
+        const int x = xs + xt * 16 + j;
+        const bool ok = xt < XT && x < W;
+#pragma unroll
+        for (int s = 0; s < KQ; ++s)
+            dst[s] = (ok && 4 * s + q < C) ? own_row[(size_t)(4 * s + q) * plane + x] : 0.f;
+    };
+    fetch_own(wave, bv);
+
+    for (int xt = wave; xt < XT; xt += NWAVE) {
+        const int x0 = xs + xt * 16;
+        if (x0 >= W) break;
+        const int x = x0 + j;
+        const bool inside = x < W;
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) bcur[s] = bv[s];
+        fetch_own(xt + NWAVE, bv);
+        // own-pixel scalars (SIDE 0: this lane's left pixel)
+        float nm_own = 0.f, out_own = 0.f, mu_own = 0.f;
+        // a masked-off own pixel takes part in no candidate (its costs were never bounded by the
+        // forward's max, so exp could overflow): all its weights are forced to 0
+        const bool own_on = inside && (SIDE == 0 ? rmask : tmask)[rowpix + (inside ? x : 0)] != 0.f;
+        if (SIDE == 0 && inside) {
+            nm_own = -max_cost[rowpix + x] * LOG2E;
+            out_own = out[rowpix + x];
+            if (VAR) mu_own = disparity[rowpix + x];
+        }
+        f32x4 gacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) gacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float gdis = 0.f;
+
+#pragma unroll 1
+        for (int m = 0; m < NT; ++m) {
+            const int ob = SIDE == 0 ? HALO + xt * 16 - 16 * m : xt * 16 + 16 * m;   // other base
+            // cost tile: rows = other pixels ob + 4q + r, columns (lanes) = own pixels
+            const float *ap = Os + q * OP + ob + j;
+            f32x4 cst = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KQ; ++s)
+                cst = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * OP], bcur[s], cst, 0, 0, 0);
+            const float4 bz = *reinterpret_cast<const float4 *>(PL + ob + 4 * q);
+            float4 nmr, outr, gsr, mur;
+            if (SIDE == 1) {
+                nmr = *reinterpret_cast<const float4 *>(PL + OW + ob + 4 * q);
+                outr = *reinterpret_cast<const float4 *>(PL + 2 * OW + ob + 4 * q);
+                gsr = *reinterpret_cast<const float4 *>(PL + 3 * OW + ob + 4 * q);
+                if (VAR) mur = *reinterpret_cast<const float4 *>(PL + 4 * OW + ob + 4 * q);
+            }
+            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+            f32x4 wt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = SIDE == 0 ? 16 * m + j - (4 * q + r) : 16 * m + (4 * q + r) - j;
+                const float nm = SIDE == 0 ? nm_own : (r == 0 ? nmr.x : r == 1 ? nmr.y : r == 2 ? nmr.z : nmr.w);
+                float cc = cst[r] + bzv[r];
+                cc = ((unsigned)d < (unsigned)D && own_on) ? cc : NEG_BIG;
+                const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm));
+                const float df = (float)d;
+                float w;
+                if (SIDE == 0) {
+                    if (VAR) {
+                        const float dd = df - mu_own;
+                        w = e * fmaf(dd, dd, -out_own);        // SV_kernel.cu:191
+                        gdis = fmaf(e, dd, gdis);              // SV_kernel.cu:321
+                    } else {
+                        w = e * (df - out_own);                // SM_kernel.cu:191
+                    }
+                } else {
+                    const float o = r == 0 ? outr.x : r == 1 ? outr.y : r == 2 ? outr.z : outr.w;
+                    const float gs = r == 0 ? gsr.x : r == 1 ? gsr.y : r == 2 ? gsr.z : gsr.w;
+                    if (VAR) {
+                        const float mu = r == 0 ? mur.x : r == 1 ? mur.y : r == 2 ? mur.z : mur.w;
+                        const float dd = df - mu;
+                        w = gs * e * fmaf(dd, dd, -o);         // SV_kernel.cu:262
+                    } else {
+                        w = gs * e * (df - o);                 // SM_kernel.cu:346
+                    }
+                }
+                wt[r] = w;
+            }
+            // contraction over the 16 other pixels of the tile: K step r uses weight register r
+            // (lane quad q <-> other pixel 4q + r) against Other[c][ob + 4q + r]
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int c = 16 * cb + cj < lo.Cq ? 16 * cb + cj : lo.Cq - 1;
+                const float4 ov = *reinterpret_cast<const float4 *>(Os + c * OP + ob + 4 * q);
+                gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0], ov.x, gacc[cb], 0, 0, 0);
+                gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1], ov.y, gacc[cb], 0, 0, 0);
+                gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[2], ov.z, gacc[cb], 0, 0, 0);
+                gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[3], ov.w, gacc[cb], 0, 0, 0);
+            }
+        }
+
+        // gacc[cb][r]: channel c = 16*cb + (lane & 15), own pixel x0 + 4q + r
+        const int xr = x0 + 4 * q;
+        float sc[4];
+        if (SIDE == 0) {
+            // grad_ref = g * sum / S (SM_kernel.cu:193); masked-off pixels stay 0 (SpaMat.py:42)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xx = xr + r;
+                sc[r] = (xx < W && rmask[rowpix + xx] != 0.f) ? grad_out[rowpix + xx] / sum_sim[rowpix + xx] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xx = xr + r;
+                sc[r] = (xx < W && tmask[rowpix + xx] != 0.f) ? 1.f : 0.f;
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int c = 16 * cb + j;
+            if (c < C) {
+                float *gp = grad_own + ((size_t)b * C + c) * plane + (size_t)y * W;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (xr + r < W) gp[xr + r] = gacc[cb][r] * sc[r];
+            }
+        }
+        if (SIDE == 0 && VAR) {
+            gdis += __shfl_xor(gdis, 16);
+            gdis += __shfl_xor(gdis, 32);
+            if (inside && q == 0) {
+                const bool on = rmask[rowpix + x] != 0.f;
+                grad_disp[rowpix + x] = on ? -2.f * grad_out[rowpix + x] * gdis / sum_sim[rowpix + x] : 0.f;
+            }
+        }
+    }
+}
+
+template <int NT, bool VAR, int KQ, int SIDE>
+int launch_side(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
+                const float *grad_out, float *grad_own, float *grad_disp, int B, int C, int H, int W,
+                int D, hipStream_t stream) {
+    constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
+    const int xt_row = ceil_div(W, 16);
+    auto bytes = [&](int xt) { return (size_t)4 * make_blayout(C, NT, xt, NPL).total; };
+    const size_t budget2 = (DECNET_LDS_BYTES - 2048) / 2, budget1 = DECNET_LDS_BYTES - 1024;
+    int XT = xt_row;
+    if (bytes(XT) > budget2) {
+        int segs = 2;
+        while (segs < xt_row && bytes(ceil_div(xt_row, segs)) > budget2) ++segs;
+        int xt2 = ceil_div(xt_row, segs);
+        if (bytes(xt2) <= budget2) XT = xt2;
+        else
+            while (XT > 1 && bytes(XT) > budget1) --XT;
+    }
+    XT = (XT + 3) & ~3;                                  // segment starts stay 64-float aligned
+    const size_t lds = bytes(XT);
+    if (lds > budget1) return DECNET_ERR_UNSUPPORTED;
+    const int segs = ceil_div(xt_row, XT);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)spamat_bwd_mfma<NT, VAR, KQ, SIDE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((spamat_bwd_mfma<NT, VAR, KQ, SIDE>), dim3((unsigned)((size_t)B * H * segs)),
+                       dim3(THREADS), lds, stream, ref, tar, rmask, tmask, disparity, out, sum_sim,
+                       max_cost, grad_out, grad_own, grad_disp, C, H, W, D, segs, XT);
+    return decnet_launch_status();
+}
+
+template <int NT, bool VAR, int KQ>
+int launch_both(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
+                const float *grad_out, float *grad_ref, float *grad_tar, float *grad_disp, int B, int C,
+                int H, int W, int D, hipStream_t stream) {
+    int rc = launch_side<NT, VAR, KQ, 0>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
+                                         grad_out, grad_ref, grad_disp, B, C, H, W, D, stream);
+    if (rc) return rc;
+    return launch_side<NT, VAR, KQ, 1>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
+                                       grad_out, grad_tar, nullptr, B, C, H, W, D, stream);
+}
+
+template <int NT, bool VAR>
+int launch_c(const float *ref, const float *tar, const float *rmask, const float *tmask,
+             const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
+             const float *grad_out, float *grad_ref, float *grad_tar, float *grad_disp, int B, int C,
+             int H, int W, int D, hipStream_t stream) {
+#define GO(K)                                                                                       \
+    return launch_both<NT, VAR, K>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,      \
+                                   grad_out, grad_ref, grad_tar, grad_disp, B, C, H, W, D, stream)
+    if (C <= 8) GO(2);
+    if (C <= 24) GO(6);
+    if (C <= 72) GO(18);
+#undef GO
+    return DECNET_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// var: 0 SpaMat, 1 SpaVar (also writes grad_disp).  DECNET_ERR_UNSUPPORTED (C > 72, band wider
+// than 18 tiles, LDS overflow) makes capi.hip fall back to the row-tile kernels.
+int decnet_mfma_backward(int var, const float *ref, const float *tar, const float *rmask,
+                         const float *tmask, const float *disparity, const float *out,
+                         const float *sum_sim, const float *max_cost, const float *grad_out,
+                         float *grad_ref, float *grad_tar, float *grad_disp, int B, int C, int H,
+                         int W, int max_disp, hipStream_t stream) {
+    const int D = max_disp;
+    const int need = D <= 1 ? 1 : (D - 1 + 15) / 16 + 1;
+    if (need > 18) return DECNET_ERR_UNSUPPORTED;
+    // the band loop is a runtime loop (nothing is kept per tile), so NT only sizes the halo
+#define GO(N)                                                                                       \
+    do {                                                                                            \
+        if (var)                                                                                    \
+            return launch_c<N, true>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,     \
+                                     grad_out, grad_ref, grad_tar, grad_disp, B, C, H, W, D, stream); \
+        return launch_c<N, false>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,        \
+                                  grad_out, grad_ref, grad_tar, grad_disp, B, C, H, W, D, stream);  \
+    } while (0)
+    if (need <= 3) GO(3);
+    if (need <= 6) GO(6);
+    if (need <= 11) GO(11);
+    if (need <= 15) GO(15);
+    GO(18);
+#undef GO
+}

@@ -14,6 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_forward_suite_with_pinned_variant(variant):
     env = dict(os.environ, DECNET_SPAMAT_KERNEL=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spamat_gpu.py"),
-                        "-m", "gpu", "-q", "-x", "-k", "forward or golden or full_size"],
+                        "-m", "gpu", "-q", "-x", "-k", "forward or golden or full_size or backward"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
