@@ -3,7 +3,8 @@
 Tolerances (fp32 path; north_star allows 1e-3 px MEAN abs diff on disparity maps):
   max_cost          : 1e-5 relative  (same c-ordered fmaf chain -> normally bit-equal)
   sum_similarities  : 2e-5 relative  (expf implementations differ by ~1 ulp per term)
-  disparity output  : max abs 2e-4 px + 1e-5 relative, and mean abs < 2e-5 px
+  disparity output  : max abs 2e-4 px + 1e-5 relative, and mean abs < 5e-5 px (values reach
+                      ~200 px where one fp32 ulp is 1.5e-5; the sums run in a different order)
   variance          : 2e-4 relative + 2e-3 abs (values reach D^2 ~ 5e4)
   gradients         : 2e-5 * max|grad| abs
 """
@@ -41,7 +42,7 @@ def check_fwd(o, s, m, out, ssum, mx, D):
     np.testing.assert_allclose(mx, m, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(ssum, s, rtol=2e-5, atol=1e-9)
     np.testing.assert_allclose(out, o, rtol=1e-5, atol=2e-4)
-    assert np.abs(out - o).mean() < 2e-5
+    assert np.abs(out - o).mean() < 5e-5
 
 
 CASES = [
@@ -125,6 +126,34 @@ def test_backward_vs_oracle(dev, B, C, H, W, D, pr, pt):
     assert np.abs(dL.grad.cpu().numpy() - gl).max() < 5e-5 * sc
     assert np.abs(dR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
     assert np.abs(dmu.grad.cpu().numpy() - gd).max() < 5e-5 * sc
+
+
+@pytest.mark.parametrize("B,C,H,W,D,p", [
+    (1, 8, 2, 1242, 216, 1.0),     # BASELINE config 3 (KITTI) stage 3: row split into segments
+    (1, 8, 2, 1242, 216, 0.15),    #   ... sparse rows -> compaction path with segments
+    (1, 8, 2, 1512, 270, 1.0),     # config 4 (Middlebury half-res) stage 3: 18-tile band
+    (1, 8, 2, 1512, 270, 0.1),
+    (1, 24, 2, 504, 90, 0.6),      # config 4 stage 2
+    (1, 72, 3, 168, 30, 1.0),      # config 4 stage 1
+    (1, 8, 1, 1100, 300, 0.5),     # band wider than the MFMA kernel covers -> row-tile fallback
+])
+def test_wide_rows_and_other_configs(dev, B, C, H, W, D, p):
+    """Shapes of BASELINE configs 3 and 4 (full width, a few rows): forward (fused) and backward."""
+    import decnet_amd
+    L, R, rm, tm = make_case(31, B, C, H, W, p, p)
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    v, _, _ = oracle.spavar_forward(L, R, rm, tm, o, D)
+    dL, dR, drm, dtm = (t.to(dev) for t in (L, R, rm, tm))
+    fo, fv, fs, fm = decnet_amd.spamatvar_forward(dL, dR, drm, dtm, D)
+    check_fwd(o, s, m, fo, fs, fm, D)
+    np.testing.assert_allclose(fv.cpu().numpy(), v, rtol=2e-4, atol=3e-3)
+    g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(6))
+    gl, gr = oracle.spamat_backward(L, R, rm, tm, o, s, m, g, D)
+    dL.requires_grad_(); dR.requires_grad_()
+    decnet_amd.SpaMatFunction.apply(dL, dR, drm, dtm, D).backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 5e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
 
 
 def test_net_callsite_golden(dev, golden_dir):
