@@ -1,0 +1,275 @@
+"""Inference graph around the hot path: this repo's counterpart of
+``modules/SparseDenseNetRefinementMask.py:102-236`` and ``modules/__init__.py:7-19``.
+
+Only the per-stage loop matters here: it is what calls the MI355X kernels (stage 0:
+``Stage0`` = cost volume + Conv3d aggregation + soft-argmax; stages 1..3: the fused
+SpaMat/SpaVar launch).  The 2-D convolution blocks either side of the path (feature extractor,
+mask generator, dynamic upsampling, soft attention, refinement -- ``modules/submodule.py:245-372,
+566-604, 666-762``) are stock convolutions and run as PyTorch-ROCm (MIOpen) ops; they are declared
+from small spec tables below with the reference's attribute names, so a reference checkpoint
+(``--resume``, demo.py:124-133) loads key-for-key.
+
+Inference only (``model.eval()``, ``torch.no_grad()``): the reference's training entry point is
+not runnable as shipped.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ops import spamatvar_forward
+from .stage0 import CostRegNetNoDown, Stage0
+
+
+class Unit(nn.Module):
+    """conv / transposed conv -> optional BatchNorm2d -> optional ReLU; attributes ``conv`` and
+    ``bn`` as in the reference's Conv2dUnit / Deconv2dUnit (submodule.py:15-87)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, relu=True, bn=True, momentum=0.1,
+                 transposed=False):
+        super().__init__()
+        if transposed:
+            self.conv = nn.ConvTranspose2d(cin, cout, k, stride=stride, padding=pad, bias=not bn)
+        else:
+            self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, dilation=dil, bias=not bn)
+        self.bn = nn.BatchNorm2d(cout, momentum=momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return F.relu(x) if self.relu else x
+
+
+def _seq(*units):
+    return nn.Sequential(*units)
+
+
+def _c3(cin, cout, **kw):
+    return Unit(cin, cout, 3, pad=kw.pop("pad", 1), **kw)
+
+
+class UpBlock(nn.Module):
+    """Deconv2dBlock (submodule.py:162-178): x3 transposed conv, concat with the skip, two 3x3."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.deconv = Unit(cin, cout, 3, stride=3, transposed=True)
+        self.conv = _seq(_c3(2 * cout, cout), _c3(cout, cout))
+
+    def forward(self, skip, x):
+        up = self.deconv(x)
+        return self.conv(torch.cat((up, skip), 1)), up
+
+
+class ASPP(nn.Module):
+    """submodule.py:225-241: a 1x1 branch and three dilated 3x3 branches, concatenated."""
+
+    def __init__(self, cin, cout, rates):
+        super().__init__()
+        self.stages = nn.Module()
+        self.stages.add_module("c0", Unit(cin, cout, 1))
+        for i, r in enumerate(rates):
+            self.stages.add_module("c%d" % (i + 1), Unit(cin, cout, 3, pad=r, dil=r))
+
+    def forward(self, x):
+        return torch.cat([s(x) for s in self.stages.children()], 1)
+
+
+class FeatExtNetChannelPlus(nn.Module):
+    """submodule.py:245-343 for num_stage=4, down_scale in {3}: 1, 1/3, 1/9, 1/27 resolution with
+    C, 3C, 9C, 27C channels; ``out_channels`` is coarse-to-fine like the reference's."""
+
+    def __init__(self, base_channels, num_stage=4, down_scale=3):
+        super().__init__()
+        assert num_stage == 4 and down_scale == 3, "the shipped configuration (demo.sh / eval.sh)"
+        c, s = base_channels, down_scale
+        c1, c2, c3 = c * s, c * s * s, c * s ** 3
+        self.conv0 = _seq(_c3(3, c), _c3(c, c))
+        self.addition_trans0 = Unit(c, c, 1)
+        self.conv1 = _seq(_c3(c, c1, stride=s), _c3(c1, c1), _c3(c1, c1))
+        self.addition_trans1 = Unit(c1, c1, 1)
+        self.deconv1 = UpBlock(c1, c)
+        self.conv2 = _seq(_c3(c1, c2, stride=s), _c3(c2, c2), _c3(c2, c2))
+        self.addition_trans2 = Unit(c2, c2, 1)
+        self.deconv2 = UpBlock(c2, c1)
+        self.conv3_1 = _c3(c2, c3, stride=s)
+        self.conv3_2 = _seq(_c3(c3, c3), _c3(c3, c3))
+        self.addition_ctx_collection = _seq(ASPP(c3, c3, [4, 8, 12]), Unit(4 * c3, c3, 1))
+        self.addition_fusion = Unit(2 * c3, c3, 1)
+        self.deconv3 = UpBlock(c3, c2)
+        self.out_channels = [c3, c2, c1, c]
+
+    def forward(self, x):
+        f0 = self.conv0(x)
+        f1 = self.conv1(f0)
+        f2 = self.conv2(f1)
+        f3a = self.conv3_1(f2)
+        f3 = self.addition_fusion(torch.cat((self.conv3_2(f3a), self.addition_ctx_collection(f3a)), 1))
+        s1, _ = self.deconv3(self.addition_trans2(f2), f3)
+        s2, _ = self.deconv2(self.addition_trans1(f1), s1)
+        s3, _ = self.deconv1(self.addition_trans0(f0), s2)
+        return {"stage0": f3, "stage1": s1, "stage2": s2, "stage3": s3}
+
+
+class GenerateSparseMask(nn.Module):
+    """submodule.py:347-372: squared difference between the level's features and the upsampled
+    previous level's, reduced to one logit per pixel."""
+
+    def __init__(self, in_channels, down_scale):
+        super().__init__()
+        self.deconv = _seq(Unit(in_channels * down_scale, 8, 3, stride=3, bn=False, transposed=True),
+                           _c3(8, 3, relu=False))
+        self.conv_sub = _seq(_c3(in_channels, 8, bn=False), _c3(8, 3, relu=False))
+        self.conv = _seq(_c3(3, 3, relu=False), Unit(3, 1, 1, relu=False))
+
+    def forward(self, cur, pre):
+        d = self.conv_sub(cur) - self.deconv(pre)
+        return self.conv(d * d).squeeze(1)
+
+
+class DynamicUpsampling(nn.Module):
+    """submodule.py:566-589: x3 upsampling of a disparity map with per-pixel softmax weights over
+    the 3x3 neighbourhood, predicted from the finer level's features."""
+
+    def __init__(self, in_channels, down_scale):
+        super().__init__()
+        self.s = down_scale
+        k = down_scale ** 2 * 9
+        self.pad = nn.ReplicationPad2d(1)
+        self.weight_learning = _seq(_c3(in_channels * down_scale ** 2 + 1, k), _c3(k, k),
+                                    _c3(k, k, relu=False))
+
+    def forward(self, disp, fea):
+        B, h, w = disp.shape
+        s2 = self.s ** 2
+        wts = torch.cat((disp.unsqueeze(1), F.unfold(fea, self.s, stride=self.s).view(B, -1, h, w)), 1)
+        wts = F.softmax(self.weight_learning(wts).view(B, s2, 9, h * w), 2)
+        nb = F.unfold(self.pad(disp.unsqueeze(1)), 3).unsqueeze(1)
+        up = (nb * wts).sum(2).view(B, s2, h, w)
+        return (F.pixel_shuffle(up, self.s) * self.s).squeeze(1)
+
+
+class SoftAttention(nn.Module):
+    """submodule.py:593-604"""
+
+    def __init__(self, in_channels, base_channels):
+        super().__init__()
+        self.conv = _seq(_c3(in_channels, base_channels), _c3(base_channels, base_channels),
+                         _c3(base_channels, 1, relu=False))
+
+    def forward(self, x):
+        return torch.sigmoid(self.conv(x))
+
+
+def warp_by_disparity(right, disp):
+    """Refinement.get_warped_feats_by_homgrp (submodule.py:719-745): the same stretched,
+    half-pixel-shifted bilinear warp as stage 0, one disparity per pixel."""
+    B, C, H, W = right.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=right.dtype, device=right.device),
+                            torch.arange(W, dtype=right.dtype, device=right.device), indexing="ij")
+    cx = (xs.unsqueeze(0) - disp) / ((W - 1.0) / 2.0) - 1.0
+    cy = (ys / ((H - 1.0) / 2.0) - 1.0).unsqueeze(0).expand_as(cx)
+    return F.grid_sample(right, torch.stack((cx, cy), 3), mode="bilinear", padding_mode="zeros",
+                         align_corners=False)
+
+
+class Refinement(nn.Module):
+    """submodule.py:666-762: residual disparity from (left, warped right, disparity)."""
+    _DIL = {0: (1, 1, 1), 1: (1, 1, 1), 2: (2, 4, 6), 3: (3, 6, 9)}
+
+    def __init__(self, in_channels, base_channels, stage_id=-1, down_scale=3):
+        super().__init__()
+        c, h = in_channels, in_channels // 2
+        d0, d2, d4 = self._DIL[stage_id]
+        self.conv = _seq(_c3(2 * c + 1, c, pad=d0, dil=d0), _c3(c, c), _c3(c, c, pad=d2, dil=d2),
+                         _c3(c, h), _c3(h, h, pad=d4, dil=d4), _c3(h, h),
+                         _c3(h, 1, relu=False, bn=False))
+
+    def forward(self, left, right, disp):
+        res = self.conv(torch.cat((left, warp_by_disparity(right, disp), disp.unsqueeze(1)), 1)).squeeze(1)
+        return disp + res, res
+
+
+class SparseDenseNetRefinementMask(nn.Module):
+    """Same constructor arguments and ``forward`` signature as the reference class
+    (SparseDenseNetRefinementMask.py:17-99, 102); inference returns ``[pred]`` (:236)."""
+
+    def __init__(self, max_disp=192, base_channels=8, num_stage=3, down_scale=3, step=(1, 2, 3),
+                 samp_num=8, sample_spa_size_list=(-1, 3, 3, 3), down_func_name="bilinear",
+                 weights=(0.2, 0.6, 1.8), grad_method="detach", cost_func="cat", if_overmask=False,
+                 skip_stage_id=3, use_detail=False, thold=0.5, alpha=0.1):
+        super().__init__()
+        assert max_disp % down_scale ** (num_stage - 1) == 0, \
+            "the max_disp({}) should be divisible by down_scale({})^num_stage({})".format(
+                max_disp, down_scale, num_stage)                      # reference :42
+        assert cost_func == "cor", "the MI355X path implements cost_func='cor' (demo.sh / eval.sh)"
+        self.max_disp, self.num_stage, self.down_scale = max_disp, num_stage, down_scale
+        self.skip_stage_id, self.use_detail, self.thold = skip_stage_id, use_detail, thold
+        self.feature_extractor = FeatExtNetChannelPlus(base_channels, num_stage, down_scale)
+        ch = self.feature_extractor.out_channels
+        self.cost_regularizer = CostRegNetNoDown(ch[0], ch[0] * 2, cost_func, down_scale)
+        n = num_stage - 1
+        self.detail_detection = nn.ModuleList(GenerateSparseMask(ch[i + 1], down_scale) for i in range(n))
+        self.dynamic_upsampling = nn.ModuleList(DynamicUpsampling(ch[i + 1], down_scale) for i in range(n))
+        self.soft_attention = nn.ModuleList(SoftAttention(ch[i + 1] + 4, base_channels) for i in range(n))
+        self.refinement = nn.ModuleList(Refinement(ch[i + 1], base_channels // 2 ** i, i + 1, down_scale)
+                                        for i in range(n))
+        # not registered as a submodule (it only wraps cost_regularizer): no duplicate state_dict keys
+        object.__setattr__(self, "_stage0", Stage0(self.cost_regularizer))
+
+    def forward(self, left, right, disparity=None, left_mask_list=None, right_mask_list=None,
+                is_check=False, is_eval=False):
+        if self.training:
+            raise NotImplementedError("inference only: call .eval() (SURVEY.md S11)")
+        lf = self.feature_extractor(left)
+        rf = self.feature_extractor(right)
+        pred = None
+        for stage in range(self.num_stage):
+            L, R = lf["stage%d" % stage], rf["stage%d" % stage]
+            cur_max_disp = self.max_disp // self.down_scale ** (self.num_stage - stage - 1)
+            if stage == 0:
+                # get_disp_samples -> GetCostVolume -> CostRegNetNoDown -> disparity_regression
+                # (reference :127-137) as one channels-last pipeline on the matrix cores
+                pred = self._stage0(L, R, cur_max_disp)
+                pre_L, pre_R = L, R
+                continue
+            if stage >= self.skip_stage_id:                               # reference :143-144
+                pred = F.interpolate(pred.unsqueeze(1) * self.down_scale, L.shape[-2:],
+                                     mode="bicubic").squeeze(1)
+                continue
+            if self.use_detail:                                           # reference :148-170
+                gen = self.detail_detection[stage - 1]
+                lmask = (torch.sigmoid(gen(L, pre_L)) > self.thold).to(L.dtype)
+                rmask = (torch.sigmoid(gen(R, pre_R)) > self.thold).to(R.dtype)
+                pre_L, pre_R = L, R
+            else:
+                lmask, rmask = left_mask_list[stage - 1], right_mask_list[stage - 1]
+            dense = self.dynamic_upsampling[stage - 1](pred, L)           # reference :178
+            # SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch
+            sparse, var, _, _ = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(),
+                                                  rmask.contiguous(), cur_max_disp)
+            soft = self.soft_attention[stage - 1](torch.cat(
+                (L, dense.unsqueeze(1), sparse.unsqueeze(1), lmask.unsqueeze(1), -var.unsqueeze(1)), 1)).squeeze(1)
+            fused = dense * (1 - soft) + soft * sparse                    # reference :202
+            pred, _ = self.refinement[stage - 1](L, R, fused)             # reference :207
+        return [pred]
+
+
+def get_model(**params):
+    """modules/__init__.py:7-19"""
+    if params["name"].lower() != "sparsedensenetrefinementmask":
+        raise Exception("No such model: {}".format(params["name"]))
+    keys = ("max_disp", "base_channels", "cost_func", "num_stage", "down_scale", "step", "samp_num",
+            "sample_spa_size_list", "down_func_name", "weights", "grad_method", "if_overmask",
+            "skip_stage_id", "use_detail", "thold")
+    return SparseDenseNetRefinementMask(**{k: params[k] for k in keys})
+
+
+def load_reference_checkpoint(model, state):
+    """demo.py:124-133: strip DataParallel's ``module.`` prefix, keep the model's own values for keys
+    the checkpoint lacks (the reference also carries parameter-free loss modules)."""
+    own = model.state_dict()
+    own.update({k.replace("module.", ""): v for k, v in state.items() if k.replace("module.", "") in own})
+    model.load_state_dict(own)
+    return model

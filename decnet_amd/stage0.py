@@ -161,10 +161,22 @@ class CostRegNetNoDown(nn.Module):
             for i, u in enumerate(units):
                 w = u.conv.weight.detach().float().contiguous()
                 Co, Ci = int(w.shape[0]), int(w.shape[1])
+                # the kernels move channels in 16-byte groups: channel counts that are not a
+                # multiple of 4 (never the case for the shipped 216-channel net) run zero padded
+                cip = (Ci + 3) & ~3
+                cop = (Co + 3) & ~3 if i < 7 else 1
+                if cip != Ci or cop != Co:
+                    wpad = torch.zeros((cop, cip) + tuple(w.shape[2:]), dtype=w.dtype, device=dev)
+                    wpad[:Co, :Ci] = w
+                    w = wpad
                 bn = u.bn
                 eps = float(bn.eps)
                 scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + eps))
                 shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+                if i < 7 and cop != Co:                 # padded output channels stay exactly 0
+                    scale = torch.cat((scale, torch.ones(cop - Co, device=dev)))
+                    shift = torch.cat((shift, torch.zeros(cop - Co, device=dev)))
+                Co, Ci = cop, cip
                 if i < 7:
                     CoP = L.decnet_conv3d_packed_cout(Co)
                     if CoP < 0:
@@ -198,8 +210,12 @@ class CostRegNetNoDown(nn.Module):
         _chk("cost volume", x)
         B, D, H, W, C = x.shape
         P = self.prepare()
+        c_true = int(self.units()[0].conv.weight.shape[1])
+        if C == c_true and P[0]["Ci"] != C:             # channel count not a multiple of 4: zero pad
+            x = torch.nn.functional.pad(x, (0, P[0]["Ci"] - C))
+            C = P[0]["Ci"]
         if P[0]["Ci"] != C:
-            raise ValueError("cost volume has %d channels, module expects %d" % (C, P[0]["Ci"]))
+            raise ValueError("cost volume has %d channels, module expects %d" % (C, c_true))
         L = _lib.lib()
         dev = x.device
         a, b, c = self._workspace(dev, B * D * H * W * C)
@@ -263,6 +279,10 @@ class Stage0(nn.Module):
     def forward(self, left_feature_map, right_feature_map, max_disp, return_reg=False):
         left = left_feature_map.contiguous()
         right = right_feature_map.contiguous()
+        if left.shape[1] % 4:                           # see CostRegNetNoDown.prepare
+            padc = (0, 0, 0, 0, 0, 4 - left.shape[1] % 4)
+            left = torch.nn.functional.pad(left, padc)
+            right = torch.nn.functional.pad(right, padc)
         B, C, H, W = left.shape
         D = int(max_disp)
         key = (left.device, B, D, H, W, C)

@@ -169,6 +169,42 @@ def net_case():
     return rec
 
 
+E2E_KW = dict(name="sparsedensenetrefinementmask", max_disp=216, base_channels=2, cost_func="cor",
+              grad_method="detach", num_stage=4, down_scale=3, step=[-1., 1., 1., 1.],
+              samp_num=[-1., 12., 10., 6.], sample_spa_size_list=[-1, 3, 5, 7], down_func_name="bicubic",
+              weights=[1., 1., 1., 1.], if_overmask=False, skip_stage_id=4, use_detail=True, thold=0.5)
+
+
+def e2e_inputs(seed=99, H=54, W=243):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(1, 3, H, W, generator=g), torch.randn(1, 3, H, W, generator=g)
+
+
+def e2e_case():
+    """Whole reference graph (base_channels=2 so that the run is small) with seeded synthetic
+    parameters (tests/golden/netparams.py -- regenerated by the test, not stored): the network's
+    final disparity and the per-stage sparse results.  SpaMat/SpaVar are the oracle stub."""
+    from modules import get_model
+    from netparams import fill_state_dict
+    model = get_model(**E2E_KW)
+    model.load_state_dict(fill_state_dict(model.state_dict()))
+    model.eval()
+    rec = {}
+    for i in range(3):
+        model.sparse_matching[i].register_forward_hook(
+            lambda m, inp, out, i=i: rec.__setitem__("sparse%d" % (i + 1), out.numpy().copy()) or
+            rec.__setitem__("lmask%d" % (i + 1), inp[2].numpy().copy()))
+    left, right = e2e_inputs()
+    H, W = left.shape[-2:]
+    lm = [torch.ones(1, H // 9, W // 9), torch.ones(1, H // 3, W // 3), torch.ones(1, H, W)]
+    with torch.no_grad():
+        pred = model(left, right, torch.zeros(1, H, W), lm, lm, is_check=False, is_eval=False)[-1]
+    rec["pred"] = pred.numpy()
+    rec["input_checksum"] = np.float64(left.double().sum().item() + right.double().abs().sum().item())
+    rec["w_checksum"] = np.float64(sum(v.double().abs().sum().item() for v in model.state_dict().values()))
+    return rec
+
+
 def main():
     install_stubs()
     import modules.submodule as sub
@@ -182,6 +218,11 @@ def main():
         if getattr(v, "ndim", 0) >= 2 and k.endswith("mask"):
             print(k, v.shape, "density %.3f" % float((v != 0).mean()))
     np.savez_compressed(os.path.join(HERE, "net_54x243.npz"), **rec)
+    sys.path.insert(0, HERE)
+    e2e = e2e_case()
+    for i in (1, 2, 3):
+        print("e2e lmask%d density %.3f" % (i, float((e2e["lmask%d" % i] != 0).mean())))
+    np.savez_compressed(os.path.join(HERE, "e2e_bc2_54x243.npz"), **e2e)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
