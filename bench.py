@@ -151,6 +151,32 @@ def cpu_baseline(seed=17):
                       "C/OpenMP SpaMat+SpaVar stages 1-3 %.2f s" % (t_s0, t_sp)}
 
 
+def e2e_bench(B, dev, iters=5):
+    """Whole network forward (random-init weights, demo.sh hyper-parameters, thold 0.5 so that the
+    untrained mask generator produces mixed masks) on B synthetic 960x540 pairs padded to 972x540."""
+    from decnet_amd.model import get_model
+    torch.manual_seed(17)
+    model = get_model(name="sparsedensenetrefinementmask", max_disp=MAX_DISP, base_channels=8, cost_func="cor",
+                      grad_method="detach", num_stage=4, down_scale=3, step=[-1., 1., 1., 1.],
+                      samp_num=[-1., 12., 10., 6.], sample_spa_size_list=[-1, 3, 5, 7],
+                      down_func_name="bicubic", weights=[1., 1., 1., 1.], if_overmask=False, skip_stage_id=4,
+                      use_detail=True, thold=0.5).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(17)
+    left = torch.randn(B, 3, PAD_H, PAD_W, device=dev, generator=g)
+    right = torch.randn(B, 3, PAD_H, PAD_W, device=dev, generator=g)
+    with torch.no_grad():
+        for _ in range(2):
+            model(left, right)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model(left, right)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    return {"value": B / dt, "unit": "pairs/s", "ms_per_batch": 1e3 * dt, "batch": B,
+            "note": "full graph: MIOpen 2-D convs (PyTorch-ROCm) + the MI355X hot-path kernels"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +185,9 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=8)
     ap.add_argument("--mask-density", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the whole inference graph (decnet_amd.model: MIOpen 2-D convs around "
+                         "the hot path) on the same batch and report it as an extra 'e2e' object")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -264,6 +293,8 @@ def main():
         }
         if sparse:
             out["roofline_costvol_sparse"] = sparse
+        if args.e2e:
+            out["e2e"] = e2e_bench(B, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

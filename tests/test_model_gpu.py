@@ -79,3 +79,22 @@ def test_e2e_against_reference_graph():
     print("e2e: mean abs diff %.2e px over %.1f%% clean pixels, max %.2e; overall mean %.2e"
           % (err[clean].mean(), 100 * clean.mean(), err[clean].max(), err.mean()))
     assert err[clean].mean() < 1e-3
+
+
+def test_demo_counterpart_runs_on_a_directory(tmp_path):
+    """demo.py flow end to end on two synthetic pairs (one with calib.txt): PNG out, right size."""
+    from PIL import Image
+    from decnet_amd import demo
+    rng = np.random.RandomState(0)
+    for name, (h, w) in (("a", (40, 100)), ("b", (54, 81))):
+        d = tmp_path / "in" / name
+        d.mkdir(parents=True)
+        for f in ("im0.png", "im1.png"):
+            Image.fromarray(rng.randint(0, 255, (h, w, 3)).astype(np.uint8)).save(str(d / f))
+    (tmp_path / "in" / "b" / "calib.txt").write_text("ndisp=40\n")          # -> max_disp 54
+    args = demo.build_parser().parse_args(["--root", str(tmp_path / "in"), "--save2where", str(tmp_path / "out"),
+                                           "--base_channels", "2", "--max_disp", "216", "--thold", "0.5"])
+    demo.test(args)
+    a = np.asarray(Image.open(str(tmp_path / "out" / "a.png")))
+    b = np.asarray(Image.open(str(tmp_path / "out" / "b.png")))
+    assert a.shape == (40, 100) and b.shape == (54, 81) and a.dtype == np.uint16
