@@ -33,7 +33,7 @@
 
 #ifndef DECNET_ABLATE
 #define DECNET_ABLATE 0   // 1: skip MFMAs, 2: skip softmax passes, 3: both (diagnostic builds only,
-#endif                    // tools/ablate_spamat.sh; results are wrong by construction)
+#endif                    // tools/ablate.sh; results are wrong by construction)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
