@@ -37,10 +37,10 @@ constexpr int B_PITCH = 240;   // == 16 (mod 32): rows kq, kq+1 land on opposite
 // One workgroup per (b, y): the left row and the two right rows the bilinear taps touch are read
 // once, x-contiguous (NCHW), into LDS; every (d, x, c) product is then formed from LDS and
 // written c-contiguous (channels-last), so both HBM sides are coalesced.
-__global__ __launch_bounds__(256) void costvol_cor_ndhwc(const float *__restrict__ left,
+__global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict__ left,
                                                          const float *__restrict__ right,
                                                          float *__restrict__ cost, int C, int H,
-                                                         int W, int D) {
+                                                         int W, int D, int dchunk) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int WP = W | 1;                      // odd pitch: column reads across c are conflict-free
@@ -62,11 +62,13 @@ __global__ __launch_bounds__(256) void costvol_cor_ndhwc(const float *__restrict
         R1[c * WP + x] = (y1 >= 0 && y1 < H) ? Rb[c * plane + (size_t)y1 * W + x] : 0.f;
     }
     __syncthreads();
-    const int n = D * W * C;
+    // blockIdx.y picks a chunk of disparities (more workgroups than the B*H rows alone)
+    const int d_lo = blockIdx.y * dchunk, d_hi = min(D, d_lo + dchunk);
+    const int n = (d_hi - d_lo) * W * C;
     float *out = cost + (size_t)b * D * plane * C + (size_t)y * W * C;     // + d*plane*C + x*C + c
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         int c = i % C, t = i / C;
-        int x = t % W, d = t / W;
+        int x = t % W, d = d_lo + t / W;
         float l = x >= d ? Ls[c * WP + x] : 0.f;                  // submodule.py:506-508
         float cx = (float)(x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
         float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f;
@@ -610,8 +612,9 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H)), dim3(256), lds, (hipStream_t)stream,
-                       left, right, cost, C, H, W, D);
+    const int dchunk = D >= 8 ? 2 : 1;
+    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H), (unsigned)ceil_div(D, dchunk)),
+                       dim3(512), lds, (hipStream_t)stream, left, right, cost, C, H, W, D, dchunk);
     return decnet_launch_status();
 }
 

@@ -13,6 +13,8 @@ reference loads unchanged.  Activations between the HIP kernels are channels-las
 Inference (eval mode, no autograd) only: the reference's training path through these
 modules is not runnable as shipped and is outside the hot-path scope.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -20,6 +22,15 @@ from . import _lib
 from .ops import _chk, _stream
 
 BN_EPS = 1e-5
+
+
+def conv_algo():
+    """"winograd" (default: F(2x2x2,3x3x3), 3.4x fewer multiplications) or "direct" (27-tap implicit
+    GEMM); DECNET_CONV_ALGO overrides.  Both are fp32 on the matrix cores and agree to ~1e-6."""
+    a = os.environ.get("DECNET_CONV_ALGO", "winograd").lower()
+    if a not in ("winograd", "direct"):
+        raise ValueError("DECNET_CONV_ALGO must be 'winograd' or 'direct'")
+    return a
 
 
 def get_disp_samples(max_dis, feature_map, stage_id=0, disprity_map=None, step=1, samp_num=9,
@@ -185,7 +196,10 @@ class CostRegNetNoDown(nn.Module):
                     wp = torch.empty((27, Ci, CoP), dtype=torch.float32, device=dev)
                     _lib.check(L.decnet_conv3d_pack_weight(w.data_ptr(), wp.data_ptr(), Co, Ci,
                                                            stream), "decnet_conv3d_pack_weight")
-                    packed.append(dict(w=wp, scale=scale.contiguous(), shift=shift.contiguous(),
+                    wu = torch.empty(L.decnet_conv3d_wino_weight_floats(Ci), dtype=torch.float32, device=dev)
+                    _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), wu.data_ptr(), Co, Ci,
+                                                                stream), "decnet_conv3d_wino_pack_weight")
+                    packed.append(dict(w=wp, u=wu, scale=scale.contiguous(), shift=shift.contiguous(),
                                        Ci=Ci, Co=Co, relu=1 if u.relu else 0, keep=w))
                 else:
                     assert Co == 1
@@ -222,12 +236,28 @@ class CostRegNetNoDown(nn.Module):
         reg = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_reg else None
         pred = torch.empty((B, H, W), dtype=torch.float32, device=dev)
 
+        wino = conv_algo() == "winograd"
+        wsp = None
+        if wino:
+            n = L.decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C)
+            wsp = self._ws.get(("wino", dev))
+            if wsp is None or wsp.numel() < n:
+                wsp = torch.empty(n, dtype=torch.float32, device=dev)
+                self._ws[("wino", dev)] = wsp
+
         def conv(i, src, dst, res=None):
             p = P[i]
-            rc = L.decnet_conv3d_bn_act(src.data_ptr(), p["w"].data_ptr(), p["scale"].data_ptr(),
-                                        p["shift"].data_ptr(), res.data_ptr() if res is not None else None,
-                                        dst.data_ptr(), B, D, H, W, p["Ci"], p["Co"], p["relu"], st)
-            _lib.check(rc, "decnet_conv3d_bn_act[%d]" % i)
+            r = res.data_ptr() if res is not None else None
+            if wino:
+                rc = L.decnet_conv3d_wino_bn_act(src.data_ptr(), p["u"].data_ptr(), p["scale"].data_ptr(),
+                                                 p["shift"].data_ptr(), r, dst.data_ptr(), wsp.data_ptr(),
+                                                 B, D, H, W, p["Ci"], p["Co"], p["relu"], st)
+                _lib.check(rc, "decnet_conv3d_wino_bn_act[%d]" % i)
+            else:
+                rc = L.decnet_conv3d_bn_act(src.data_ptr(), p["w"].data_ptr(), p["scale"].data_ptr(),
+                                            p["shift"].data_ptr(), r, dst.data_ptr(), B, D, H, W,
+                                            p["Ci"], p["Co"], p["relu"], st)
+                _lib.check(rc, "decnet_conv3d_bn_act[%d]" % i)
 
         with torch.cuda.device(dev):
             st = _stream(x)

@@ -118,6 +118,20 @@ int decnet_conv3d_bn_act(const float *x, const float *w_packed, const float *sca
                          const float *shift, const float *residual, float *y, int B, int D,
                          int H, int W, int Ci, int Co, int relu, void *stream);
 
+/* The same Conv3dUnit by Winograd F(2x2x2, 3x3x3) (fp32, 3.375x fewer multiplications; differs
+ * from decnet_conv3d_bn_act by fp32 rounding only, ~1e-6 relative).
+ *   u          weights transformed once by decnet_conv3d_wino_pack_weight:
+ *              [Co,Ci,3,3,3] -> [64, Ci, 224]  (decnet_conv3d_wino_weight_floats(Ci) floats)
+ *   workspace  decnet_conv3d_wino_workspace_floats(B,D,H,W,Ci,Co) floats of device scratch
+ *   everything else as decnet_conv3d_bn_act.                                                */
+size_t decnet_conv3d_wino_weight_floats(int Ci);
+int decnet_conv3d_wino_pack_weight(const float *w_oidhw, float *u, int Co, int Ci, void *stream);
+size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co);
+int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale,
+                              const float *shift, const float *residual, float *y,
+                              float *workspace, int B, int D, int H, int W, int Ci, int Co,
+                              int relu, void *stream);
+
 /* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
  * over disp_samples = arange(D) (submodule.py:766-777):
  *   reg[b,d,y,x]  = conv(x)[b,d,y,x] * scale + shift        (optional output, may be NULL)
