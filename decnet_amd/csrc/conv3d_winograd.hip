@@ -13,6 +13,8 @@
 //
 // Tiles are processed in chunks sized so that a chunk's V and M (64 x tiles x C floats each) stay
 // in the 256 MiB Infinity Cache between the three kernels of the chunk.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -190,7 +192,12 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, int vof
 template <int WM, int BK>
 __global__ __launch_bounds__(WM * 128) void wino_gemm(const float *__restrict__ Vb,
                                                      const float *__restrict__ Ub,
-                                                     float *__restrict__ Mb, int nt, int Ci, int Co) {
+                                                     float *__restrict__ Mb, int nt, int Ci, int Co,
+                                                     int xg) {
+    // blockIdx.y owns xg consecutive transform points xi and runs them as ONE software pipeline
+    // (the first K chunk of point xi+1 is prefetched during the last K chunk of point xi, the
+    // accumulators are stored and cleared at the boundary): K = Ci alone is only 6 chunks, too
+    // short to hide a pipeline fill per point.
     constexpr int THREADS = WM * 128, BM = WM * 48, TM = 3, TN = 7;
     constexpr int A_PITCH = BK + 2;
     constexpr int A_F4 = BM * (BK / 4);
@@ -204,12 +211,9 @@ __global__ __launch_bounds__(WM * 128) void wino_gemm(const float *__restrict__ 
     float *As = smem;
     float *Bs = smem + 2 * A_TILE;
 
-    const int xi = blockIdx.y;
-    const float *V = Vb + (size_t)xi * nt * Ci;
-    const float *U = Ub + (size_t)xi * Ci * W_BN;
-    float *Mo = Mb + (size_t)xi * nt * Co;
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, nt * Ci * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)U, 0, Ci * W_BN * 4, 0x00020000);
+    const int xi0 = blockIdx.y * xg;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, 64 * nt * Ci * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ub, 0, 64 * Ci * W_BN * 4, 0x00020000);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -235,20 +239,23 @@ __global__ __launch_bounds__(WM * 128) void wino_gemm(const float *__restrict__ 
         b_off[i] = idx < B_F4 ? (kk * W_BN + 4 * q) * 4 : OOB;
         b_k[i] = kk;
     }
-    const int nstep = (Ci + BK - 1) / BK;
+    const int nchunk = (Ci + BK - 1) / BK;
+    const int nstep = xg * nchunk;
+    const int v_point = nt * Ci * 4, u_point = Ci * W_BN * 4;         // bytes per transform point
 
     float4 ra[A_PER_T], rb[B_PER_T];
     auto prefetch = [&](int s) {
-        const int ci0 = s * BK;
+        const int p = s / nchunk, ci0 = (s - p * nchunk) * BK;
+        const int va = (xi0 + p) * v_point + ci0 * 4, ua = (xi0 + p) * u_point + ci0 * W_BN * 4;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const bool ok = a_off[i] != OOB && ci0 + a_k[i] < Ci;
-            ra[i] = buf_load4(vr, ok ? a_off[i] + ci0 * 4 : OOB);
+            ra[i] = buf_load4(vr, ok ? a_off[i] + va : OOB);
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const bool ok = b_off[i] != OOB && ci0 + b_k[i] < Ci;
-            rb[i] = buf_load4(ur, ok ? b_off[i] + ci0 * W_BN * 4 : OOB);
+            rb[i] = buf_load4(ur, ok ? b_off[i] + ua : OOB);
         }
     };
     auto stage = [&](int buf) {
@@ -275,6 +282,7 @@ __global__ __launch_bounds__(WM * 128) void wino_gemm(const float *__restrict__ 
     __syncthreads();
     const int a_row0 = (wm * 48 + i16) * A_PITCH + kq;
     const int b_col0 = kq * WB_PITCH + wn * (W_BN / 2) + i16;
+    int chunk = 0, point = xi0;
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstep) prefetch(s + 1);
@@ -294,19 +302,25 @@ __global__ __launch_bounds__(WM * 128) void wino_gemm(const float *__restrict__ 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (s + 1 < nstep) stage(buf ^ 1);
-        __syncthreads();
-    }
+        if (++chunk == nchunk) {                       // transform point finished: store and clear
+            float *Mo = Mb + (size_t)point * nt * Co;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = wn * (W_BN / 2) + j * 16 + i16;
-        if (co >= Co) continue;
+            for (int j = 0; j < TN; ++j) {
+                const int co = wn * (W_BN / 2) + j * 16 + i16;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_block + wm * 48 + i * 16 + kq * 4 + r;
-                if (m < nt) Mo[(size_t)m * Co + co] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m_block + wm * 48 + i * 16 + kq * 4 + r;
+                        if (co < Co && m < nt) Mo[(size_t)m * Co + co] = acc[i][j][r];
+                    }
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
+            chunk = 0;
+            ++point;
+        }
+        __syncthreads();
     }
 }
 
@@ -319,15 +333,25 @@ int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((wino_gemm<WM, BK>), dim3(ceil_div(nt, BM), 64), dim3(WM * 128), lds, stream, V, U,
-                       M, nt, Ci, Co);
+    // transform points per workgroup: as many as keeps >= ~1 workgroup per CU
+    const int mblocks = ceil_div(nt, BM);
+    int xg = 64;
+    while (xg > 1 && (long)mblocks * (64 / xg) < 240) xg >>= 1;
+    static const int xg_env = [] { const char *e = getenv("DECNET_WINO_XG"); return e ? atoi(e) : 0; }();
+    if (xg_env > 0) xg = xg_env;
+    hipLaunchKernelGGL((wino_gemm<WM, BK>), dim3(mblocks, 64 / xg), dim3(WM * 128), lds, stream, V, U, M,
+                       nt, Ci, Co, xg);
     return decnet_launch_status();
 }
 
 // tiles per chunk: V and M of one chunk (2 * 64 * nt * C floats) should stay Infinity-Cache
 // resident (256 MiB) between the three kernels of the chunk; equal chunks
 int chunk_tiles(int T, int C) {
-    long cap = (long)(160.0 * 1024 * 1024 / (2.0 * 64 * 4 * C));
+    static const double cap_mb = [] {
+        const char *e = getenv("DECNET_WINO_CHUNK_MB");       // experiments: V+M bytes per chunk
+        return e ? atof(e) : 160.0;
+    }();
+    long cap = (long)(cap_mb * 1024 * 1024 / (2.0 * 64 * 4 * C));
     if (cap < 192) cap = 192;
     const long nchunks = (T + cap - 1) / cap;          // equal chunks
     return (int)((T + nchunks - 1) / nchunks);
@@ -370,7 +394,7 @@ int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale
     const int T = (int)Td;
     const int cmax = Ci > Co ? Ci : Co;
     const int ct = chunk_tiles(T, cmax);
-    if ((double)ct * cmax * 4 >= 2147483647.0) return DECNET_ERR_UNSUPPORTED;
+    if ((double)ct * cmax * 4 * 64 >= 2147483647.0) return DECNET_ERR_UNSUPPORTED;   // 32-bit offsets
     float *V = workspace, *M = workspace + (size_t)64 * ct * Ci;
     hipStream_t s = (hipStream_t)stream;
     for (int t_lo = 0; t_lo < T; t_lo += ct) {
@@ -381,10 +405,13 @@ int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale
         int rc = decnet_launch_status();
         if (rc) return rc;
         // tile height: one round of 192-row blocks when that fills the chip, else 96-row blocks
-        if (Ci % 36 == 0 && (long)ceil_div(nt, 192) * 64 >= 256)
-            rc = launch_gemm<4, 36>(V, u, M, nt, Ci, Co, s);
-        else
+        static const int tile_env = [] { const char *e = getenv("DECNET_WINO_TILE"); return e ? atoi(e) : 0; }();
+        if (tile_env == 96 || !(Ci % 36 == 0 && (long)ceil_div(nt, 192) * 64 >= 256))
             rc = launch_gemm<2, 24>(V, u, M, nt, Ci, Co, s);
+        else if (tile_env == 19224)
+            rc = launch_gemm<4, 24>(V, u, M, nt, Ci, Co, s);
+        else
+            rc = launch_gemm<4, 36>(V, u, M, nt, Ci, Co, s);
         if (rc) return rc;
         n = (size_t)nt * Co;
         hipLaunchKernelGGL(wino_output_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M,

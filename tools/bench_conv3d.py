@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--ci", type=int, default=216)
     ap.add_argument("--co", type=int, default=216)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--algo", default="direct", choices=["direct", "winograd"])
     a = ap.parse_args()
     D, H, W = map(int, a.shape.split(","))
     B, Ci, Co = a.batch, a.ci, a.co
@@ -33,9 +34,18 @@ def main():
     sc, sh = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
     y = torch.empty(B, D, H, W, Co, device=dev)
 
+    if a.algo == "winograd":
+        u = torch.empty(L.decnet_conv3d_wino_weight_floats(Ci), device=dev)
+        _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), u.data_ptr(), Co, Ci, st), "wpack")
+        ws = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D, H, W, Ci, Co), device=dev)
+
     def run():
-        _lib.check(L.decnet_conv3d_bn_act(x.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(), None,
-                                          y.data_ptr(), B, D, H, W, Ci, Co, 1, st), "conv")
+        if a.algo == "winograd":
+            _lib.check(L.decnet_conv3d_wino_bn_act(x.data_ptr(), u.data_ptr(), sc.data_ptr(), sh.data_ptr(), None,
+                                                   y.data_ptr(), ws.data_ptr(), B, D, H, W, Ci, Co, 1, st), "wino")
+        else:
+            _lib.check(L.decnet_conv3d_bn_act(x.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(), None,
+                                              y.data_ptr(), B, D, H, W, Ci, Co, 1, st), "conv")
     for _ in range(3):
         run()
     beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,6 +57,7 @@ def main():
     ms = beg.elapsed_time(end) / a.iters
     M = B * D * H * W
     flop = 2.0 * 27 * Ci * Co * M
+    print(a.algo, end=" ")
     print("conv3d B=%d D=%d H=%d W=%d Ci=%d Co=%d (M=%d): %.4f ms  %.1f TFLOP/s (%.1f%% of 157.3)"
           % (B, D, H, W, Ci, Co, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 1.573))
 
