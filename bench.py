@@ -238,24 +238,41 @@ def main():
             pass
         ms_step = 1e3 * elapsed / args.steps
         pairs = world * B * args.steps
-        # --- dominant kernel: conv3d_k3_igemm (7 launches inside stage 0), live events -------
+        # --- dominant kernel, timed live with events on the launch stream -------------------
         C0, H0, W0, D0 = STAGES[0]
         M = B * D0 * H0 * W0
-        conv_flop = 2.0 * 27 * C0 * C0 * M
+        conv_flop = 2.0 * 27 * C0 * C0 * M                      # direct-convolution flops of one layer
         s0_ms = sum(e["s0_beg"].elapsed_time(e["s0_end"]) for e in ev) / args.steps
         with torch.no_grad():
             cv = hp.stage0._cv[next(iter(hp.stage0._cv))]
             P = hp.reg.prepare()
             from decnet_amd import _lib
+            from decnet_amd.stage0 import conv_algo
             L = _lib.lib()
             a, b, _ = hp.reg._workspace(dev, cv.numel())
             st = torch.cuda.current_stream().cuda_stream
-
-            def one_conv():
-                p = P[0]
-                L.decnet_conv3d_bn_act(cv.data_ptr(), p["w"].data_ptr(), p["scale"].data_ptr(),
-                                       p["shift"].data_ptr(), None, a.data_ptr(), B, D0, H0, W0, C0, C0, 1, st)
-            conv_ms = time_kernel(one_conv, 10)
+            p0 = P[0]
+            if conv_algo() == "winograd":
+                # one Conv3d layer = input transform + 64 batched GEMMs + output transform; the GEMM
+                # kernel (wino_gemm) is the dominant kernel of the step
+                nt = B * ((D0 + 1) // 2) * ((H0 + 1) // 2) * ((W0 + 1) // 2)
+                wsp = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D0, H0, W0, C0, C0), device=dev)
+                V, Mw = wsp[:64 * nt * C0], wsp[64 * nt * C0:]
+                layer_ms = time_kernel(lambda: L.decnet_conv3d_wino_bn_act(
+                    cv.data_ptr(), p0["u"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr(), None,
+                    a.data_ptr(), wsp.data_ptr(), B, D0, H0, W0, C0, C0, 1, st), 10)
+                conv_ms = time_kernel(lambda: L.decnet_conv3d_wino_gemm(
+                    V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, st), 10)
+                kern_flop = 2.0 * 64 * nt * C0 * C0
+                kern_name = "wino_gemm (64 x [%d x %d] x [%d x %d], Winograd F(2x2x2,3x3x3) Conv3d 216->216)" % (nt, C0, C0, C0)
+                tkey = "wino_gemm"
+            else:
+                conv_ms = layer_ms = time_kernel(lambda: L.decnet_conv3d_bn_act(
+                    cv.data_ptr(), p0["w"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr(), None,
+                    a.data_ptr(), B, D0, H0, W0, C0, C0, 1, st), 10)
+                kern_flop = conv_flop
+                kern_name = "conv3d_k3_igemm (216->216, 3^3, M=%d)" % M
+                tkey = "conv3d_k3_igemm"
             # --- cost-volume pass (fused SpaMat+SpaVar, stage 3), live events + both densities
             C3, H3, W3, D3 = STAGES[3]
             s3_bytes = 4.0 * B * H3 * W3 * (2 * C3 + 2 + 4)
@@ -279,11 +296,12 @@ def main():
                                    "random-init CostRegNetNoDown(216)" % B,
                        "pairs_per_gpu": B, "mask_density": args.mask_density,
                        "parallelism": "dp%d (pairs sharded, all_gather of disparity maps)" % world},
-            "roofline": {"bound": "mfma", "achieved": conv_flop / conv_ms / 1e9, "peak": MFMA_F32_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": conv_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
-                         "traffic": traffic.get("conv3d_k3_igemm", {}).get("total_bytes"),
-                         "kernel": "conv3d_k3_igemm (216->216, 3^3, M=%d)" % M,
-                         "ms": conv_ms, "flop_per_launch": conv_flop, "stage0_ms_in_step": s0_ms},
+            "roofline": {"bound": "mfma", "achieved": kern_flop / conv_ms / 1e9, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": kern_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
+                         "traffic": traffic.get(tkey, {}).get("total_bytes"), "kernel": kern_name,
+                         "ms": conv_ms, "flop_per_launch": kern_flop, "stage0_ms_in_step": s0_ms,
+                         "conv3d_layer_ms": layer_ms,
+                         "conv3d_layer_direct_equiv_tflops": conv_flop / layer_ms / 1e9},
             "roofline_costvol": {"bound": "hbm", "achieved": s3_bytes / s3_ms / 1e6, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": s3_bytes / s3_ms / 1e6 / HBM_PEAK_GBS,
                                  "traffic": traffic.get("spamat_fused_stage3", {}).get("total_bytes"),

@@ -11,8 +11,10 @@
 // regularised volume differs from the direct convolution by 1e-6 relative, the disparity by
 // 2e-5 px (tests/test_stage0_gpu.py checks both algorithms against the same oracle).
 //
-// Tiles are processed in chunks sized so that a chunk's V and M (64 x tiles x C floats each) stay
-// in the 256 MiB Infinity Cache between the three kernels of the chunk.
+// Tiles are processed in chunks of at most 1 GiB of V + M (64 x tiles x C floats each); chunks
+// small enough to stay in the 256 MiB Infinity Cache between the three kernels were measured
+// and gain nothing (the transforms already run at 4.3-5.3 TB/s), while one big chunk lets a GEMM
+// workgroup pipeline 8 transform points back to back.
 #include <stdlib.h>
 
 #include "common.h"
@@ -344,12 +346,11 @@ int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co
     return decnet_launch_status();
 }
 
-// tiles per chunk: V and M of one chunk (2 * 64 * nt * C floats) should stay Infinity-Cache
-// resident (256 MiB) between the three kernels of the chunk; equal chunks
+// tiles per chunk: V + M of one chunk (2 * 64 * nt * C floats) <= DECNET_WINO_CHUNK_MB (1 GiB); equal chunks
 int chunk_tiles(int T, int C) {
     static const double cap_mb = [] {
         const char *e = getenv("DECNET_WINO_CHUNK_MB");       // experiments: V+M bytes per chunk
-        return e ? atof(e) : 160.0;
+        return e ? atof(e) : 1024.0;
     }();
     long cap = (long)(cap_mb * 1024 * 1024 / (2.0 * 64 * 4 * C));
     if (cap < 192) cap = 192;
@@ -371,6 +372,19 @@ int decnet_conv3d_wino_pack_weight(const float *w, float *u, int Co, int Ci, voi
     hipLaunchKernelGGL(wino_weight_transform, dim3(ceil_div(n, 128)), dim3(128), 0, (hipStream_t)stream,
                        w, u, Co, Ci);
     return decnet_launch_status();
+}
+
+/* The batched GEMM stage alone (measurement / composition): M[xi] = V[xi] * U[xi], xi = 0..63,
+ * V [64][nt][Ci], U from decnet_conv3d_wino_pack_weight, M [64][nt][Co]. */
+int decnet_conv3d_wino_gemm(const float *V, const float *u, float *M, int nt, int Ci, int Co,
+                            void *stream) {
+    if (!V || !u || !M) return DECNET_ERR_NULL_POINTER;
+    if (nt < 1 || Ci < 1 || Co < 1) return DECNET_ERR_BAD_SHAPE;
+    if (Ci % 4 != 0 || Co > W_BN || (double)nt * (Ci > Co ? Ci : Co) * 256 >= 2147483647.0)
+        return DECNET_ERR_UNSUPPORTED;
+    if (Ci % 36 == 0 && (long)ceil_div(nt, 192) * 64 >= 256)
+        return launch_gemm<4, 36>(V, u, M, nt, Ci, Co, (hipStream_t)stream);
+    return launch_gemm<2, 24>(V, u, M, nt, Ci, Co, (hipStream_t)stream);
 }
 
 size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co) {

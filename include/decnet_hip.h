@@ -127,6 +127,10 @@ int decnet_conv3d_bn_act(const float *x, const float *w_packed, const float *sca
 size_t decnet_conv3d_wino_weight_floats(int Ci);
 int decnet_conv3d_wino_pack_weight(const float *w_oidhw, float *u, int Co, int Ci, void *stream);
 size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co);
+/* its GEMM stage alone: M[xi] = V[xi] * U[xi] for the 64 transform points xi;
+ * V [64][nt][Ci] (transformed input tiles), M [64][nt][Co]. */
+int decnet_conv3d_wino_gemm(const float *V, const float *u, float *M, int nt, int Ci, int Co,
+                            void *stream);
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale,
                               const float *shift, const float *residual, float *y,
                               float *workspace, int B, int D, int H, int W, int Ci, int Co,
