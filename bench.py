@@ -247,24 +247,27 @@ def main():
             cv = hp.stage0._cv[next(iter(hp.stage0._cv))]
             P = hp.reg.prepare()
             from decnet_amd import _lib
-            from decnet_amd.stage0 import conv_algo
+            from decnet_amd.stage0 import conv_algo, WINO_VARIANT
             L = _lib.lib()
             a, b, _ = hp.reg._workspace(dev, cv.numel())
             st = torch.cuda.current_stream().cuda_stream
             p0 = P[0]
-            if conv_algo() == "winograd":
-                # one Conv3d layer = input transform + 64 batched GEMMs + output transform; the GEMM
-                # kernel (wino_gemm) is the dominant kernel of the step
-                nt = B * ((D0 + 1) // 2) * ((H0 + 1) // 2) * ((W0 + 1) // 2)
-                wsp = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D0, H0, W0, C0, C0), device=dev)
-                V, Mw = wsp[:64 * nt * C0], wsp[64 * nt * C0:]
+            if conv_algo() in WINO_VARIANT:
+                # one Conv3d layer = input transform + batched GEMMs (one per transform point) + output
+                # transform; the GEMM kernel (wino_gemm) is the dominant kernel of the step
+                var = WINO_VARIANT[conv_algo()]
+                oh, npts = (2, 64) if var == 0 else (4, 144)
+                nt = B * ((D0 + 1) // 2) * ((H0 + oh - 1) // oh) * ((W0 + oh - 1) // oh)
+                wsp = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D0, H0, W0, C0, C0, var), device=dev)
+                V, Mw = wsp[:npts * nt * C0], wsp[npts * nt * C0:]
                 layer_ms = time_kernel(lambda: L.decnet_conv3d_wino_bn_act(
                     cv.data_ptr(), p0["u"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr(), None,
-                    a.data_ptr(), wsp.data_ptr(), B, D0, H0, W0, C0, C0, 1, st), 10)
+                    a.data_ptr(), wsp.data_ptr(), B, D0, H0, W0, C0, C0, 1, var, st), 10)
                 conv_ms = time_kernel(lambda: L.decnet_conv3d_wino_gemm(
-                    V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, st), 10)
-                kern_flop = 2.0 * 64 * nt * C0 * C0
-                kern_name = "wino_gemm (64 x [%d x %d] x [%d x %d], Winograd F(2x2x2,3x3x3) Conv3d 216->216)" % (nt, C0, C0, C0)
+                    V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, var, st), 10)
+                kern_flop = 2.0 * npts * nt * C0 * C0
+                kern_name = "wino_gemm (%d x [%d x %d] x [%d x %d], %s Conv3d 216->216)" % (
+                    npts, nt, C0, C0, C0, "Winograd F(2,3)^3" if var == 0 else "Winograd F(2,3)xF(4,3)^2")
                 tkey = "wino_gemm"
             else:
                 conv_ms = layer_ms = time_kernel(lambda: L.decnet_conv3d_bn_act(

@@ -25,11 +25,11 @@ SIGNATURES = {
     "decnet_conv3d_packed_cout": [_I],
     "decnet_conv3d_pack_weight": [_P, _P, _I, _I, _P],
     "decnet_conv3d_bn_act": [_P] * 6 + [_I] * 7 + [_P],
-    "decnet_conv3d_wino_weight_floats": [_I],
-    "decnet_conv3d_wino_pack_weight": [_P, _P, _I, _I, _P],
-    "decnet_conv3d_wino_workspace_floats": [_I] * 6,
-    "decnet_conv3d_wino_bn_act": [_P] * 7 + [_I] * 7 + [_P],
-    "decnet_conv3d_wino_gemm": [_P] * 3 + [_I] * 3 + [_P],
+    "decnet_conv3d_wino_weight_floats": [_I, _I],
+    "decnet_conv3d_wino_pack_weight": [_P, _P, _I, _I, _I, _P],
+    "decnet_conv3d_wino_workspace_floats": [_I] * 7,
+    "decnet_conv3d_wino_bn_act": [_P] * 7 + [_I] * 8 + [_P],
+    "decnet_conv3d_wino_gemm": [_P] * 3 + [_I] * 4 + [_P],
     "decnet_conv3d_cout1_softargmax": [_P, _P, _F, _F, _P, _P] + [_I] * 5 + [_P],
     "decnet_disparity_regression": [_P] * 3 + [_I] * 4 + [_P],
     "decnet_ncdhw_to_ndhwc": [_P, _P] + [_I] * 5 + [_P],

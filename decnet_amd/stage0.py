@@ -24,12 +24,16 @@ from .ops import _chk, _stream
 BN_EPS = 1e-5
 
 
+WINO_VARIANT = {"winograd": 0, "winograd4": 1}
+
+
 def conv_algo():
-    """"winograd" (default: F(2x2x2,3x3x3), 3.4x fewer multiplications) or "direct" (27-tap implicit
-    GEMM); DECNET_CONV_ALGO overrides.  Both are fp32 on the matrix cores and agree to ~1e-6."""
+    """"winograd" (default: F(2,3) on D,H,W, 3.4x fewer multiplications), "winograd4" (F(2,3) on D,
+    F(4,3) on H and W, 6x fewer) or "direct" (27-tap implicit GEMM); DECNET_CONV_ALGO overrides.
+    All are fp32 on the matrix cores; they differ by fp32 rounding only (~1e-6 / ~6e-6 relative)."""
     a = os.environ.get("DECNET_CONV_ALGO", "winograd").lower()
-    if a not in ("winograd", "direct"):
-        raise ValueError("DECNET_CONV_ALGO must be 'winograd' or 'direct'")
+    if a not in ("winograd", "winograd4", "direct"):
+        raise ValueError("DECNET_CONV_ALGO must be 'winograd', 'winograd4' or 'direct'")
     return a
 
 
@@ -157,7 +161,8 @@ class CostRegNetNoDown(nn.Module):
     def prepare(self):
         """Repack the 7 wide Conv3d weights to [27,Ci,CoP] on the device and fold eval-mode
         BatchNorm into per-channel scale/shift.  Cached until a parameter changes."""
-        key = self._key()
+        algo = conv_algo()
+        key = (algo,) + self._key()
         if self._packed is not None and key == self._packed_key:
             return self._packed
         units = self.units()
@@ -196,9 +201,13 @@ class CostRegNetNoDown(nn.Module):
                     wp = torch.empty((27, Ci, CoP), dtype=torch.float32, device=dev)
                     _lib.check(L.decnet_conv3d_pack_weight(w.data_ptr(), wp.data_ptr(), Co, Ci,
                                                            stream), "decnet_conv3d_pack_weight")
-                    wu = torch.empty(L.decnet_conv3d_wino_weight_floats(Ci), dtype=torch.float32, device=dev)
-                    _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), wu.data_ptr(), Co, Ci,
-                                                                stream), "decnet_conv3d_wino_pack_weight")
+                    wu = None
+                    if algo in WINO_VARIANT:
+                        var = WINO_VARIANT[algo]
+                        wu = torch.empty(L.decnet_conv3d_wino_weight_floats(Ci, var), dtype=torch.float32,
+                                         device=dev)
+                        _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), wu.data_ptr(), Co, Ci, var,
+                                                                    stream), "decnet_conv3d_wino_pack_weight")
                     packed.append(dict(w=wp, u=wu, scale=scale.contiguous(), shift=shift.contiguous(),
                                        Ci=Ci, Co=Co, relu=1 if u.relu else 0, keep=w))
                 else:
@@ -236,10 +245,11 @@ class CostRegNetNoDown(nn.Module):
         reg = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_reg else None
         pred = torch.empty((B, H, W), dtype=torch.float32, device=dev)
 
-        wino = conv_algo() == "winograd"
+        wino = conv_algo() in WINO_VARIANT
         wsp = None
         if wino:
-            n = L.decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C)
+            var = WINO_VARIANT[conv_algo()]
+            n = L.decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, var)
             wsp = self._ws.get(("wino", dev))
             if wsp is None or wsp.numel() < n:
                 wsp = torch.empty(n, dtype=torch.float32, device=dev)
@@ -251,7 +261,7 @@ class CostRegNetNoDown(nn.Module):
             if wino:
                 rc = L.decnet_conv3d_wino_bn_act(src.data_ptr(), p["u"].data_ptr(), p["scale"].data_ptr(),
                                                  p["shift"].data_ptr(), r, dst.data_ptr(), wsp.data_ptr(),
-                                                 B, D, H, W, p["Ci"], p["Co"], p["relu"], st)
+                                                 B, D, H, W, p["Ci"], p["Co"], p["relu"], var, st)
                 _lib.check(rc, "decnet_conv3d_wino_bn_act[%d]" % i)
             else:
                 rc = L.decnet_conv3d_bn_act(src.data_ptr(), p["w"].data_ptr(), p["scale"].data_ptr(),

@@ -118,23 +118,26 @@ int decnet_conv3d_bn_act(const float *x, const float *w_packed, const float *sca
                          const float *shift, const float *residual, float *y, int B, int D,
                          int H, int W, int Ci, int Co, int relu, void *stream);
 
-/* The same Conv3dUnit by Winograd F(2x2x2, 3x3x3) (fp32, 3.375x fewer multiplications; differs
- * from decnet_conv3d_bn_act by fp32 rounding only, ~1e-6 relative).
+/* The same Conv3dUnit by Winograd minimal filtering in fp32 (differs from decnet_conv3d_bn_act by
+ * fp32 rounding only).  variant 0: F(2,3) on D,H,W -- 64 transform points, 8 multiplies per output
+ * instead of 27, ~1e-6 relative;  variant 1: F(2,3) on D, F(4,3) on H and W -- 144 points, 4.5
+ * multiplies per output, ~6e-6 relative.
  *   u          weights transformed once by decnet_conv3d_wino_pack_weight:
- *              [Co,Ci,3,3,3] -> [64, Ci, 224]  (decnet_conv3d_wino_weight_floats(Ci) floats)
- *   workspace  decnet_conv3d_wino_workspace_floats(B,D,H,W,Ci,Co) floats of device scratch
+ *              [Co,Ci,3,3,3] -> [points, Ci, 224]  (decnet_conv3d_wino_weight_floats floats)
+ *   workspace  decnet_conv3d_wino_workspace_floats(...) floats of device scratch
  *   everything else as decnet_conv3d_bn_act.                                                */
-size_t decnet_conv3d_wino_weight_floats(int Ci);
-int decnet_conv3d_wino_pack_weight(const float *w_oidhw, float *u, int Co, int Ci, void *stream);
-size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co);
-/* its GEMM stage alone: M[xi] = V[xi] * U[xi] for the 64 transform points xi;
- * V [64][nt][Ci] (transformed input tiles), M [64][nt][Co]. */
+size_t decnet_conv3d_wino_weight_floats(int Ci, int variant);
+int decnet_conv3d_wino_pack_weight(const float *w_oidhw, float *u, int Co, int Ci, int variant,
+                                   void *stream);
+size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co, int variant);
+/* its GEMM stage alone: M[xi] = V[xi] * U[xi] for every transform point xi;
+ * V [points][nt][Ci] (transformed input tiles), M [points][nt][Co]. */
 int decnet_conv3d_wino_gemm(const float *V, const float *u, float *M, int nt, int Ci, int Co,
-                            void *stream);
+                            int variant, void *stream);
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale,
                               const float *shift, const float *residual, float *y,
                               float *workspace, int B, int D, int H, int W, int Ci, int Co,
-                              int relu, void *stream);
+                              int relu, int variant, void *stream);
 
 /* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
  * over disp_samples = arange(D) (submodule.py:766-777):

@@ -5,6 +5,7 @@
 #                                   4 compact path: staging+compaction only | 5 staging only
 #   Conv3d          -DDECNET_CONV_ABLATE=1 no prefetch | 2 no MFMA | 3 no barrier | 4 no LDS staging |
 #                                   5 pure MFMA stream | 6 MFMA + LDS fragment reads
+#   Winograd GEMM   -DDECNET_WINO_ABLATE=1 no stores | 2 no global loads | 3 no MFMA | 5 neither loads nor stores
 # Use:  tools/ablate.sh && DECNET_HIP_LIB=$PWD/tools/ubench/libdecnet_abl2.so python tools/bench_spamat.py
 set -e
 cd "$(dirname "$0")/.."
@@ -12,9 +13,13 @@ S=decnet_amd/csrc
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared"
 for a in 1 2 3 4 5; do
   hipcc $COMMON -fno-honor-nans -DDECNET_ABLATE=$a $S/spamat_mfma.hip $S/spamat_bwd_mfma.hip $S/capi.hip \
-        $S/spamat_rowtile.hip $S/stage0.hip -o tools/ubench/libdecnet_abl$a.so
+        $S/spamat_rowtile.hip $S/stage0.hip $S/conv3d_winograd.hip -o tools/ubench/libdecnet_abl$a.so
 done
 for a in 1 2 3 4 5 6; do
   hipcc $COMMON -DDECNET_CONV_ABLATE=$a $S/stage0.hip $S/capi.hip $S/spamat_rowtile.hip \
-        $S/spamat_bwd_mfma.hip -fno-honor-nans $S/spamat_mfma.hip -o tools/ubench/libdecnet_cabl$a.so
+        $S/spamat_bwd_mfma.hip -fno-honor-nans $S/spamat_mfma.hip $S/conv3d_winograd.hip -o tools/ubench/libdecnet_cabl$a.so
+done
+for a in 1 2 3 5; do
+  hipcc $COMMON -DDECNET_WINO_ABLATE=$a $S/conv3d_winograd.hip $S/stage0.hip $S/capi.hip $S/spamat_rowtile.hip \
+        $S/spamat_bwd_mfma.hip -fno-honor-nans $S/spamat_mfma.hip -o tools/ubench/libdecnet_wabl$a.so
 done

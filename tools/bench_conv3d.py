@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--ci", type=int, default=216)
     ap.add_argument("--co", type=int, default=216)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--algo", default="direct", choices=["direct", "winograd"])
+    ap.add_argument("--algo", default="direct", choices=["direct", "winograd", "winograd4"])
     a = ap.parse_args()
     D, H, W = map(int, a.shape.split(","))
     B, Ci, Co = a.batch, a.ci, a.co
@@ -34,15 +34,16 @@ def main():
     sc, sh = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
     y = torch.empty(B, D, H, W, Co, device=dev)
 
-    if a.algo == "winograd":
-        u = torch.empty(L.decnet_conv3d_wino_weight_floats(Ci), device=dev)
-        _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), u.data_ptr(), Co, Ci, st), "wpack")
-        ws = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D, H, W, Ci, Co), device=dev)
+    var = {"winograd": 0, "winograd4": 1}.get(a.algo, -1)
+    if a.algo != "direct":
+        u = torch.empty(L.decnet_conv3d_wino_weight_floats(Ci, var), device=dev)
+        _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), u.data_ptr(), Co, Ci, var, st), "wpack")
+        ws = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D, H, W, Ci, Co, var), device=dev)
 
     def run():
-        if a.algo == "winograd":
+        if a.algo != "direct":
             _lib.check(L.decnet_conv3d_wino_bn_act(x.data_ptr(), u.data_ptr(), sc.data_ptr(), sh.data_ptr(), None,
-                                                   y.data_ptr(), ws.data_ptr(), B, D, H, W, Ci, Co, 1, st), "wino")
+                                                   y.data_ptr(), ws.data_ptr(), B, D, H, W, Ci, Co, 1, var, st), "wino")
         else:
             _lib.check(L.decnet_conv3d_bn_act(x.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(), None,
                                               y.data_ptr(), B, D, H, W, Ci, Co, 1, st), "conv")
