@@ -259,7 +259,8 @@ def main():
                 oh, npts = (2, 64) if var == 0 else (4, 144)
                 nt = B * ((D0 + 1) // 2) * ((H0 + oh - 1) // oh) * ((W0 + oh - 1) // oh)
                 wsp = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D0, H0, W0, C0, C0, var), device=dev)
-                V, Mw = wsp[:npts * nt * C0], wsp[npts * nt * C0:]
+                cp = (C0 + 15) // 16 * 16
+                V, Mw = wsp[:npts * nt * cp], wsp[npts * nt * cp:]
                 layer_ms = time_kernel(lambda: L.decnet_conv3d_wino_bn_act(
                     cv.data_ptr(), p0["u"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr(), None,
                     a.data_ptr(), wsp.data_ptr(), B, D0, H0, W0, C0, C0, 1, var, st), 10)

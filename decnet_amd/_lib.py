@@ -31,6 +31,8 @@ SIGNATURES = {
     "decnet_conv3d_wino_bn_act": [_P] * 7 + [_I] * 8 + [_P],
     "decnet_conv3d_wino_gemm": [_P] * 3 + [_I] * 4 + [_P],
     "decnet_conv3d_cout1_softargmax": [_P, _P, _F, _F, _P, _P] + [_I] * 5 + [_P],
+    "decnet_conv3d_cout1_workspace_floats": [_I] * 4,
+    "decnet_conv3d_cout1_softargmax_ws": [_P, _P, _F, _F, _P, _P, _P] + [_I] * 5 + [_P],
     "decnet_disparity_regression": [_P] * 3 + [_I] * 4 + [_P],
     "decnet_ncdhw_to_ndhwc": [_P, _P] + [_I] * 5 + [_P],
     "decnet_ndhwc_to_ncdhw": [_P, _P] + [_I] * 5 + [_P],

@@ -1,42 +1,50 @@
-// decnet_amd/csrc/conv3d_winograd.hip -- Conv3d(k3,s1,p1)+BN+ReLU by Winograd F(2x2x2, 3x3x3) in
-// fp32 on the matrix cores (gfx950).  Same operator as stage0.hip:conv3d_k3_igemm -- one
-// Conv3dUnit of CostRegNetNoDown in eval mode (submodule.py:115-123, 608-662) -- with 3.375x
-// fewer multiplications: every 2x2x2 block of outputs is computed from a 4x4x4 input tile as
+// decnet_amd/csrc/conv3d_winograd.hip -- Conv3d(k3,s1,p1)+BN+ReLU by Winograd minimal filtering in
+// fp32 on the matrix cores (gfx950).  Same operator as stage0.hip:conv3d_k3_igemm -- one Conv3dUnit
+// of CostRegNetNoDown in eval mode (submodule.py:115-123, 608-662) -- with 3.4x / 6x fewer
+// multiplications: every block of outputs is computed from an input tile as
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A        (applied along D, H and W)
-// so the 27-tap implicit GEMM (K = 27*Ci) becomes 64 independent GEMMs with K = Ci:
-//     M[xi][tile][co] = sum_ci V[xi][tile][ci] * U[xi][ci][co],   xi = 0..63
+// so the 27-tap implicit GEMM (K = 27*Ci) becomes one small GEMM with K = Ci per transform point:
+//     M[xi][tile][co] = sum_ci V[xi][tile][ci] * U[xi][ci][co]
 //   V = B^T-transformed input tiles (adds only), U = G-transformed weights (once per weight
 //   version), Y = A^T-transformed M (adds only) -> BN scale/shift -> ReLU -> (+ residual).
 // fp32 throughout.  Two tile shapes (the `variant` argument of the entry points):
 //   0  F(2,3) on D, H and W: 4x4x4 input tile -> 2x2x2 outputs, 64 transform points, 8 multiplies
-//      per output (27 direct).  Benign constants (0, +-1, +-1/2): on the 8-layer stack the
-//      regularised volume differs from the direct convolution by 1e-6 relative, the disparity by
-//      2e-5 px max.
+//      per output (27 direct).  Constants 0, +-1, +-1/2: as accurate as the direct convolution
+//      (tools/conv_numerics.py, against float64: 1.8e-6 relative on the regularised volume, the
+//      direct kernel 2.9e-6, torch CPU 1.5e-6).
 //   1  F(2,3) on D, F(4,3) on H and W: 4x6x6 tile -> 2x4x4 outputs, 144 points, 4.5 multiplies
-//      per output; constants up to 8 and 1/24: 6e-6 relative on the volume, 1.2e-4 px max /
-//      1e-5 px mean on the disparity (still 10x / 100x inside the 1e-3 px budget).
+//      per output; constants up to 8 and 1/24: 6.0e-6 relative on the volume, 2.3e-5 px mean on
+//      the disparity (direct: 1.1e-5) -- 40x inside the 1e-3 px budget.
 // tests/test_stage0_gpu.py checks every algorithm against the same oracle.
 //
-// Tiles are processed in chunks of at most 1 GiB of V + M (64 x tiles x C floats each); chunks
-// small enough to stay in the 256 MiB Infinity Cache between the three kernels were measured
-// and gain nothing (the transforms already run at 4.3-5.3 TB/s), while one big chunk lets a GEMM
-// workgroup pipeline 8 transform points back to back.
+// Layout of the three intermediates ("chunk major": 16 channels = 64 bytes are the unit):
+//     V   [point][ceil(Ci/16)][tile][16]      U^T [point][ceil(Ci/16)][224 co][16]
+//     M   [point][ceil(Co/16)][tile][16]
+// so that (a) a wave of the GEMM reads the 16 rows x 16 k of an MFMA operand as ONE contiguous
+// 1 KiB load and writes a 16x16 result tile as one contiguous 1 KiB store, and (b) a wave of the
+// transform kernels (16 channels x 4 tiles) moves 256 contiguous bytes per transform point.
+//
+// Tiles are processed in chunks of at most 1 GiB of V + M; chunks small enough to stay in the
+// 256 MiB Infinity Cache between the three kernels were measured and gain nothing.
 #include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "common.h"
 
 #ifndef DECNET_WINO_ABLATE
-#define DECNET_WINO_ABLATE 0     // timing-only builds (tools/ablate.sh): 1 no stores | 2 no global loads |
-#endif                           // 3 no MFMA | 5 neither loads nor stores
+#define DECNET_WINO_ABLATE 0     // timing-only builds (tools/ablate.sh): 1 no stores | 2 loads always hit |
+#endif                           // 3 no MFMA | 5 = 1 + 2 | 6 no loads
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int W_BN = 224;      // co tile of the GEMM, 14 MFMA tiles of 16 (as conv3d_k3_igemm)
-constexpr int WB_PITCH = 240;  // == 16 (mod 32)
+constexpr int W_BN = 224;      // co rows of U^T per transform point: 14 MFMA tiles of 16
 
 // 1-D transforms of F(m,3), m = O outputs, tile T = O + 2 (Lavin & Gray, arXiv:1509.09308)
 template <int T> __device__ __forceinline__ void bt_1d(float (&v)[T]);
@@ -79,14 +87,15 @@ template <> __device__ __forceinline__ void at_1d<6>(const float (&m)[6], float 
 }
 
 // ------------------------------ weight transform (once) --------------------------------
-// w [Co][Ci][3][3][3] (torch) -> U [TD*TH*TW][Ci][224], U = G w G^T along the three axes, co padded.
-// kt != 0: U^T [points][224][Ci] (k contiguous) for wino_gemm_reg.
+// w [Co][Ci][3][3][3] (torch) -> U^T [TD*TH*TW][ceil(Ci/16)][224][16], U = G w G^T along the three
+// axes; co >= Co rows are zero, ci >= Ci slots of the last chunk are never read.
 template <int TD, int TH, int TW>
 __global__ void wino_weight_transform(const float *__restrict__ w, float *__restrict__ U, int Co,
-                                      int Ci, int kt) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (ci, co)
+                                      int Ci) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (co, ci), ci fastest
     if (idx >= Ci * W_BN) return;
-    const int co = idx % W_BN, ci = idx / W_BN;
+    const int ci = idx % Ci, co = idx / Ci;
+    const int KC = (Ci + 15) >> 4;
     float t1[3][3][TW], t2[3][TH][TW];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -107,6 +116,8 @@ __global__ void wino_weight_transform(const float *__restrict__ w, float *__rest
 #pragma unroll
             for (int jj = 0; jj < TH; ++jj) t2[i][jj][k] = o[jj];
         }
+    float *up = U + ((size_t)(ci >> 4) * W_BN + co) * 16 + (ci & 15);
+    const size_t ps = (size_t)KC * W_BN * 16;
 #pragma unroll
     for (int jj = 0; jj < TH; ++jj)
 #pragma unroll
@@ -115,10 +126,7 @@ __global__ void wino_weight_transform(const float *__restrict__ w, float *__rest
             float o[TD];
             g_1d<TD>(g, o);
 #pragma unroll
-            for (int i = 0; i < TD; ++i) {
-                const size_t pt = (size_t)((i * TH + jj) * TW + k);
-                U[kt ? (pt * W_BN + co) * Ci + ci : (pt * Ci + ci) * W_BN + co] = o[i];
-            }
+            for (int i = 0; i < TD; ++i) up[(size_t)((i * TH + jj) * TW + k) * ps] = o[i];
         }
 }
 
@@ -135,17 +143,30 @@ __device__ __forceinline__ void tile_coords(int t, const Tiling &g, int &b, int 
 }
 
 // ------------------------------ input transform -----------------------------------------
-// x [B,D,H,W,C] -> V[xi][tile - t_lo][c], V = B^T d B along D, H, W.  One thread per (tile, channel),
-// channel fastest (coalesced on both sides).
+// x [B,D,H,W,C] -> V[xi][c/16][tile - t_lo][c%16], V = B^T d B along D, H, W.  One thread per
+// (16-channel group, tile, channel in group): a wave is 4 tiles x 16 channels.
 template <int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void wino_input_transform(const float *__restrict__ x,
                                                             float *__restrict__ V, Tiling g, int C,
-                                                            int t_lo, int nt) {
+                                                            int t_lo, int nt, int x_bytes) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)nt * C) return;
-    const int c = (int)(idx % C), tl = (int)(idx / C);
+    const int KC = (C + 15) >> 4;
+#ifdef DECNET_WINO_MAP1
+    const int tl = (int)(idx / (KC * 16)), c = (int)(idx - (size_t)tl * (KC * 16)), kc = c >> 4;
+    if (tl >= nt || c >= C) return;
+#else
+    const size_t q = idx >> 4;
+    const int kc = (int)(q / nt), tl = (int)(q - (size_t)kc * nt);
+    const int c = kc * 16 + (int)(idx & 15);
+    if (kc >= KC || c >= C) return;
+#endif
     int b, z0, y0, x0;
     tile_coords<TD - 2, TH - 2, TW - 2>(t_lo + tl, g, b, z0, y0, x0);
+    // branch-free halo: out-of-volume taps are sent past the end of the buffer and read as zeros, so
+    // all TD*TH*TW loads of a thread are in flight together (with branches the compiler waits for
+    // every row of loads before the next)
+    constexpr int OOB = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
     float d[TD][TH][TW];
 #pragma unroll
     for (int i = 0; i < TD; ++i) {
@@ -154,11 +175,15 @@ __global__ __launch_bounds__(256) void wino_input_transform(const float *__restr
         for (int jj = 0; jj < TH; ++jj) {
             const int y = y0 - 1 + jj;
             const bool okzy = (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H;
-            const float *row = x + (((size_t)b * g.D + z) * g.H + y) * g.W * C + c;
+            const int row = ((((b * g.D + z) * g.H + y) * g.W + x0 - 1) * C + c) * 4;
 #pragma unroll
             for (int k = 0; k < TW; ++k) {
-                const int xx = x0 - 1 + k;
-                d[i][jj][k] = (okzy && (unsigned)xx < (unsigned)g.W) ? row[(size_t)xx * C] : 0.f;
+                const bool ok = okzy && (unsigned)(x0 - 1 + k) < (unsigned)g.W;
+#if DECNET_WINO_ABLATE == 7
+                d[i][jj][k] = ok ? (float)(k + i) : 0.f;
+#else
+                d[i][jj][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, ok ? row + k * C * 4 : OOB, 0, 0));
+#endif
             }
         }
     }
@@ -188,32 +213,39 @@ __global__ __launch_bounds__(256) void wino_input_transform(const float *__restr
 #pragma unroll
             for (int i = 0; i < TD; ++i) d[i][jj][k] = v[i];
         }
-    float *o = V + (size_t)tl * C + c;
-    const size_t xs = (size_t)nt * C;
+    float *o = V + ((size_t)kc * nt + tl) * 16 + (c & 15);
+    const size_t xs = (size_t)KC * nt * 16;
 #pragma unroll
     for (int i = 0; i < TD; ++i)
 #pragma unroll
         for (int jj = 0; jj < TH; ++jj)
 #pragma unroll
+#if DECNET_WINO_ABLATE == 8
+            for (int k = 0; k < TW; ++k) { if (d[i][jj][k] == 12345.678f) o[(size_t)((i * TH + jj) * TW + k) * xs] = d[i][jj][k]; }
+#else
             for (int k = 0; k < TW; ++k) o[(size_t)((i * TH + jj) * TW + k) * xs] = d[i][jj][k];
+#endif
 }
 
 // ------------------------------ output transform + epilogue -----------------------------
-// M[xi][tile - t_lo][co] -> y: A^T along W, H, D, then BN scale/shift, ReLU, + residual
-// (CostRegNetNoDown.forward submodule.py:656).
+// M[xi][co/16][tile - t_lo][co%16] -> y: A^T along W, H, D, then BN scale/shift, ReLU, + residual
+// (CostRegNetNoDown.forward submodule.py:656).  Thread mapping as the input transform.
 template <int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void wino_output_transform(
     const float *__restrict__ M, const float *__restrict__ scale, const float *__restrict__ shift,
     const float *__restrict__ residual, float *__restrict__ y, Tiling g, int Co, int relu, int t_lo,
-    int nt) {
+    int nt, int y_bytes) {
     constexpr int OD = TD - 2, OH = TH - 2, OW = TW - 2;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)nt * Co) return;
-    const int co = (int)(idx % Co), tl = (int)(idx / Co);
+    const int CG = (Co + 15) >> 4;
+    const size_t q = idx >> 4;
+    const int cg = (int)(q / nt), tl = (int)(q - (size_t)cg * nt);
+    const int co = cg * 16 + (int)(idx & 15);
+    if (cg >= CG || co >= Co) return;
     int b, z0, y0, x0;
     tile_coords<OD, OH, OW>(t_lo + tl, g, b, z0, y0, x0);
-    const float *mp = M + (size_t)tl * Co + co;
-    const size_t xs = (size_t)nt * Co;
+    const float *mp = M + ((size_t)cg * nt + tl) * 16 + (idx & 15);
+    const size_t xs = (size_t)CG * nt * 16;
     float a[TD][TH][OW], bb[TD][OH][OW];
 #pragma unroll
     for (int i = 0; i < TD; ++i)
@@ -221,7 +253,11 @@ __global__ __launch_bounds__(256) void wino_output_transform(
         for (int jj = 0; jj < TH; ++jj) {
             float m[TW];
 #pragma unroll
+#if DECNET_WINO_ABLATE == 7
+            for (int k = 0; k < TW; ++k) m[k] = (float)(k + i + jj + tl);
+#else
             for (int k = 0; k < TW; ++k) m[k] = mp[(size_t)((i * TH + jj) * TW + k) * xs];
+#endif
             at_1d<TW>(m, a[i][jj]);
         }
 #pragma unroll
@@ -236,6 +272,12 @@ __global__ __launch_bounds__(256) void wino_output_transform(
             for (int jj = 0; jj < OH; ++jj) bb[i][jj][k] = o[jj];
         }
     const float sc = scale[co], sh = shift[co];
+    // branch-free epilogue (buffer accesses past the end are dropped / read as zero): the residual
+    // loads of all outputs are in flight together
+    constexpr int OOB = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(residual ? residual : y), 0, y_bytes, 0x00020000);
+    float out[OD][OH][OW], res[OD][OH][OW];
 #pragma unroll
     for (int jj = 0; jj < OH; ++jj)
 #pragma unroll
@@ -247,48 +289,68 @@ __global__ __launch_bounds__(256) void wino_output_transform(
 #pragma unroll
             for (int i = 0; i < OD; ++i) {
                 const int z = z0 + i, yy = y0 + jj, xx = x0 + k;
-                if (z < g.D && yy < g.H && xx < g.W) {
-                    float v = fmaf(o[i], sc, sh);
-                    if (relu) v = fmaxf(v, 0.f);
-                    const size_t off = ((((size_t)b * g.D + z) * g.H + yy) * g.W + xx) * Co + co;
-                    if (residual) v += residual[off];
-                    y[off] = v;
-                }
+                const int off = z < g.D && yy < g.H && xx < g.W
+                                    ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
+                res[i][jj][k] = residual ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, off, 0, 0)) : 0.f;
+                float v = fmaf(o[i], sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+                out[i][jj][k] = v;
             }
         }
+#pragma unroll
+    for (int i = 0; i < OD; ++i)
+#pragma unroll
+        for (int jj = 0; jj < OH; ++jj)
+#pragma unroll
+            for (int k = 0; k < OW; ++k) {
+                const int z = z0 + i, yy = y0 + jj, xx = x0 + k;
+#if DECNET_WINO_ABLATE == 8
+                const int off = OOB;
+#else
+                const int off = z < g.D && yy < g.H && xx < g.W
+                                    ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
+#endif
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(out[i][jj][k] + res[i][jj][k]), yr, off, 0, 0);
+            }
 }
 
 // ------------------------------ batched GEMM  M[xi] = V[xi] * U[xi] ----------------------
-// blockIdx.y = xi.  Rows = tiles of the chunk.  Same block / wave tiling, LDS layout and
-// prefetch scheme as conv3d_k3_igemm (WM x 2 waves, 48 x 112 per wave, double-buffered LDS,
-// bounds-checked buffer loads), with K = Ci instead of 27*Ci.
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, int voff) {
-    i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+// K = Ci is short (216), so an LDS-staged tile pipeline (the first version of this kernel: 192x224
+// tiles, double-buffered LDS as conv3d_k3_igemm) spent a quarter of its time filling and draining
+// around barriers.  Here every wave is independent: both MFMA operands go HBM/L2/L1 -> registers
+// as one 16-byte load per lane, no LDS, no barrier.  That works because the order of the K axis
+// inside an MFMA is free as long as both operands agree: lane (i16, kq) loads the four consecutive
+// k = 16c + 4kq + {0..3} of ITS row (tile m of V, or co of U^T) and MFMA step t of chunk c
+// multiplies element t of those.  With the chunk-major layouts a wave-wide operand load is 1 KiB
+// contiguous.  The operands are swapped (A = U^T rows co, B = V rows m) so that a lane's four
+// accumulator registers are four consecutive co of one tile m: the result leaves as 16-byte
+// stores, again 1 KiB contiguous per MFMA tile.  A wave owns 48 tiles x 112 co (3 x 7 MFMA tiles,
+// 84 accumulator registers) of one transform point; two waves per SIMD.  Duplicate operand reads
+// between the waves of a workgroup (V twice, U^T WM times) hit in L1/L2.
+//
+// NFULL/TAIL > 0: Ci = 16*NFULL + 4*TAIL exactly (216 = 16*13 + 4*2): the chunk loop is unrolled
+// (every s_waitcnt then counts exactly the loads that must have landed, never the stores of the
+// previous point) and the last chunk takes TAIL k per lane -- no K padding.  NFULL = 0: any Ci
+// (multiple of 4), runtime loop, last chunk zero-padded through the buffer bounds check.
+template <int N>
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+    if constexpr (N == 4) {
+        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+        return f32x4{__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)};
+    } else if constexpr (N == 2) {
+        const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
+        return f32x4{__int_as_float(v.x), __int_as_float(v.y), 0.f, 0.f};
+    } else {
+        static_assert(N == 1, "tail of 1, 2 or 4 k per lane");
+        return f32x4{__int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0)), 0.f, 0.f, 0.f};
+    }
 }
 
-template <int WM, int BK>
-__global__ __launch_bounds__(WM * 128) void wino_gemm(const float *__restrict__ Vb,
-                                                     const float *__restrict__ Ub,
-                                                     float *__restrict__ Mb, int nt, int Ci, int Co,
-                                                     int xg, int np, int swz) {
-    // blockIdx.y owns xg consecutive transform points xi and runs them as ONE software pipeline
-    // (the first K chunk of point xi+1 is prefetched during the last K chunk of point xi, the
-    // accumulators are stored and cleared at the boundary): K = Ci alone is only 6 chunks, too
-    // short to hide a pipeline fill per point.
-    constexpr int THREADS = WM * 128, BM = WM * 48, TM = 3, TN = 7;
-    constexpr int A_PITCH = BK + 2;
-    constexpr int A_F4 = BM * (BK / 4);
-    constexpr int A_PER_T = (A_F4 + THREADS - 1) / THREADS;
-    constexpr int B_F4 = BK * (W_BN / 4);
-    constexpr int B_PER_T = (B_F4 + THREADS - 1) / THREADS;
-    constexpr int A_TILE = BM * A_PITCH, B_TILE = BK * WB_PITCH;
-    constexpr int OOB = 0x7fffffff;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;
-    float *Bs = smem + 2 * A_TILE;
-
+template <int WM, int NFULL, int TAIL>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm(
+    const float *__restrict__ Vb, const float *__restrict__ Ub, float *__restrict__ Mb, int nt, int Ci,
+    int Co, int xg, int np, int swz) {
+    constexpr int TM = 3, TN = 7, BM = WM * 48, OOB = 0x7fffffff;
     // XCD-aware task order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
     // workgroup ids that are equal mod 8 take the M blocks of the SAME transform points: one XCD's
     // L2 then holds U of one point group at a time instead of every XCD streaming all of U.
@@ -299,209 +361,55 @@ __global__ __launch_bounds__(WM * 128) void wino_gemm(const float *__restrict__ 
         const int r = id / per8, q = id - r * per8;
         if (8 * (r + 1) <= ngroups) { pg = 8 * r + (q & 7); mb = q >> 3; }     // tail (< 8 groups) unswizzled
     }
-    const int xi0 = pg * xg;
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * nt * Ci * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ub, 0, np * Ci * W_BN * 4, 0x00020000);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int m_block = mb * BM;
-
-    int a_lds[A_PER_T], a_off[A_PER_T], a_k[A_PER_T];
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-        const int idx = tid + i * THREADS;
-        const int ml = idx / (BK / 4), q = idx - ml * (BK / 4);
-        const bool ok = idx < A_F4 && m_block + ml < nt;
-        a_lds[i] = idx < A_F4 ? ml * A_PITCH + 4 * q : -1;
-        a_off[i] = ok ? ((m_block + ml) * Ci + 4 * q) * 4 : OOB;
-        a_k[i] = 4 * q;
-    }
-    int b_lds[B_PER_T], b_off[B_PER_T], b_k[B_PER_T];
-#pragma unroll
-    for (int i = 0; i < B_PER_T; ++i) {
-        const int idx = tid + i * THREADS;
-        const int kk = idx / (W_BN / 4), q = idx - kk * (W_BN / 4);
-        b_lds[i] = idx < B_F4 ? kk * WB_PITCH + 4 * q : -1;
-        b_off[i] = idx < B_F4 ? (kk * W_BN + 4 * q) * 4 : OOB;
-        b_k[i] = kk;
-    }
-    const int nchunk = (Ci + BK - 1) / BK;
-    const int nstep = xg * nchunk;
-    const int v_point = nt * Ci * 4, u_point = Ci * W_BN * 4;         // bytes per transform point
-
-    float4 ra[A_PER_T], rb[B_PER_T];
-    auto prefetch = [&](int s) {
-        const int p = s / nchunk, ci0 = (s - p * nchunk) * BK;
-        const int va = (xi0 + p) * v_point + ci0 * 4, ua = (xi0 + p) * u_point + ci0 * W_BN * 4;
-#if DECNET_WINO_ABLATE == 2 || DECNET_WINO_ABLATE == 5
-        if (s > 0) return;
-#endif
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) {
-            const bool ok = a_off[i] != OOB && ci0 + a_k[i] < Ci;
-            ra[i] = buf_load4(vr, ok ? a_off[i] + va : OOB);
-        }
-#pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) {
-            const bool ok = b_off[i] != OOB && ci0 + b_k[i] < Ci;
-            rb[i] = buf_load4(ur, ok ? b_off[i] + ua : OOB);
-        }
-    };
-    auto stage = [&](int buf) {
-        float *a = As + buf * A_TILE, *b = Bs + buf * B_TILE;
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i)
-            if (a_lds[i] >= 0) {
-                *reinterpret_cast<float2 *>(a + a_lds[i]) = make_float2(ra[i].x, ra[i].y);
-                *reinterpret_cast<float2 *>(a + a_lds[i] + 2) = make_float2(ra[i].z, ra[i].w);
-            }
-#pragma unroll
-        for (int i = 0; i < B_PER_T; ++i)
-            if (b_lds[i] >= 0) *reinterpret_cast<float4 *>(b + b_lds[i]) = rb[i];
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    prefetch(0);
-    stage(0);
-    __syncthreads();
-    const int a_row0 = (wm * 48 + i16) * A_PITCH + kq;
-    const int b_col0 = kq * WB_PITCH + wn * (W_BN / 2) + i16;
-    int chunk = 0, point = xi0;
-    for (int s = 0; s < nstep; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstep) prefetch(s + 1);
-        const float *a = As + buf * A_TILE + a_row0;
-        const float *b = Bs + buf * B_TILE + b_col0;
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * A_PITCH + kk * 4];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = b[kk * 4 * WB_PITCH + j * 16];
-#if DECNET_WINO_ABLATE == 3
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][0] += av[i] * bv[j];
-#else
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-#endif
-        }
-        if (s + 1 < nstep) stage(buf ^ 1);
-        if (++chunk == nchunk) {                       // transform point finished: store and clear
-            float *Mo = Mb + (size_t)point * nt * Co;
-#if DECNET_WINO_ABLATE == 1 || DECNET_WINO_ABLATE == 5
-            if (nt > 0) Mo = nullptr;
-            if (Mo || acc[0][0][0] == 12345.f)
-#endif
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = wn * (W_BN / 2) + j * 16 + i16;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m_block + wm * 48 + i * 16 + kq * 4 + r;
-                        if (co < Co && m < nt) Mo[(size_t)m * Co + co] = acc[i][j][r];
-                    }
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            chunk = 0;
-            ++point;
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------ the same GEMM without LDS ---------------------------------
-// K = Ci is short (216), so the LDS-staged kernel above spends a quarter of its time filling and
-// draining its pipeline around barriers.  Here every wave is independent: both MFMA operands go
-// HBM/L2/L1 -> registers as one 16-byte load per lane, no LDS, no barrier.  That works because the
-// order of the K axis inside an MFMA is free as long as both operands agree: lane (i16, kq) loads
-// the four consecutive k = 16c + 4kq + {0..3} of ITS row (V row m, or U^T row co: weights are kept
-// k-contiguous, [point][224][Ci]) and MFMA step t of chunk c multiplies element t of those.
-// The operands are swapped (A = U^T rows co, B = V rows m) so that a lane's four accumulator
-// registers are four consecutive co of one tile row m: the result leaves as 16-byte stores.
-// Duplicate operand reads between the waves of a workgroup (V twice, U^T WM times) hit in L1/L2.
-// NCH > 0 (even): Ci spans exactly NCH 16-wide chunks and the chunk loop is unrolled, so every
-// s_waitcnt counts exactly the loads that must have landed (and never the stores of the previous
-// point); NCH == 0: any Ci, runtime chunk loop.
-template <int WM, int NCH>
-__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_reg(
-    const float *__restrict__ Vb, const float *__restrict__ Utb, float *__restrict__ Mb, int nt, int Ci,
-    int Co, int xg, int np, int swz) {
-    constexpr int TM = 3, TN = 7, BM = WM * 48, OOB = 0x7fffffff;
-    const int mblocks = gridDim.x, ngroups = gridDim.y;
-    int pg = blockIdx.y, mb = blockIdx.x;
-    if (swz) {                                          // XCD-aware order, as in wino_gemm
-        const int id = blockIdx.y * mblocks + blockIdx.x, per8 = 8 * mblocks;
-        const int r = id / per8, q = id - r * per8;
-        if (8 * (r + 1) <= ngroups) { pg = 8 * r + (q & 7); mb = q >> 3; }
-    }
-    const int xi0 = pg * xg;
+    const int xi0 = pg * xg;                            // this workgroup's xg consecutive points
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, kq = lane >> 4;
     const int m0 = mb * BM + wm * 48;
     if (m0 >= nt) return;                               // no barriers: idle waves of the M tail just leave
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * nt * Ci * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Utb, 0, np * Ci * W_BN * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * nt * Co * 4, 0x00020000);
-    int v_off[TM], u_off[TN], m_off[TM];
+    const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;
+    const int v_chunk = nt * 64, u_chunk = W_BN * 64;                 // bytes per 16-channel chunk
+    const int v_point = KC * v_chunk, u_point = KC * u_chunk, m_point = CG * v_chunk;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * v_point, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ub, 0, np * u_point, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * m_point, 0x00020000);
+    int v_row[TM], u_row[TN];                           // byte offset of this lane's row inside a chunk
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + i * 16 + i16;
-        v_off[i] = m < nt ? (m * Ci + kq * 4) * 4 : OOB;
-        m_off[i] = m < nt ? (m * Co + wn * (W_BN / 2) + 4 * kq) * 4 : OOB;
+        v_row[i] = m < nt ? m * 64 : OOB;
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) u_off[j] = ((wn * (W_BN / 2) + j * 16 + i16) * Ci + kq * 4) * 4;
-    const int nch = NCH > 0 ? NCH : (Ci + 15) >> 4;
-    const int v_point = nt * Ci * 4, u_point = W_BN * Ci * 4, m_point = nt * Co * 4;   // bytes per point
+    for (int j = 0; j < TN; ++j) u_row[j] = (wn * (W_BN / 2) + j * 16 + i16) * 64;
 
     f32x4 v0[TM], u0[TN], v1[TM], u1[TN];
     // (p, c) = point (relative) and chunk; beyond the last point the offsets go out of range: zeros, no traffic
-    auto load = [&](f32x4(&v)[TM], f32x4(&u)[TN], int p, int c) {
-        const bool ok = c * 16 + kq * 4 < Ci && p < xg;               // K tail: whole 16-byte groups (Ci % 4 == 0)
-#if DECNET_WINO_ABLATE == 2 || DECNET_WINO_ABLATE == 5                  // always the same (cached) lines
-        const int vb = xi0 * v_point, ub = xi0 * u_point;
-#else
-        const int vb = (xi0 + p) * v_point + c * 64, ub = (xi0 + p) * u_point + c * 64;
-#endif
-#if DECNET_WINO_ABLATE == 6                                            // no loads at all (after the first)
+    auto load = [&](f32x4(&v)[TM], f32x4(&u)[TN], int p, int c, auto nk) {
+        constexpr int NK = decltype(nk)::value;                       // k per lane in this chunk
+#if DECNET_WINO_ABLATE == 6
         if (p + c > 0) return;
 #endif
+        bool ok = p < xg;
+        if (NFULL == 0) ok = ok && c * 16 + kq * 4 < Ci;              // K tail: whole 16-byte groups (Ci % 4 == 0)
+#if DECNET_WINO_ABLATE == 2 || DECNET_WINO_ABLATE == 5
+        const int vb = xi0 * v_point + kq * (4 * NK), ub = xi0 * u_point + kq * (4 * NK);
+#else
+        const int vb = (xi0 + p) * v_point + c * v_chunk + kq * (4 * NK);
+        const int ub = (xi0 + p) * u_point + c * u_chunk + kq * (4 * NK);
+#endif
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float4 t = buf_load4(vr, ok && v_off[i] != OOB ? v_off[i] + vb : OOB);
-            v[i] = f32x4{t.x, t.y, t.z, t.w};
-        }
+        for (int i = 0; i < TM; ++i) v[i] = buf_load<NK>(vr, ok && v_row[i] != OOB ? v_row[i] + vb : OOB);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float4 t = buf_load4(ur, ok ? u_off[j] + ub : OOB);
-            u[j] = f32x4{t.x, t.y, t.z, t.w};
-        }
+        for (int j = 0; j < TN; ++j) u[j] = buf_load<NK>(ur, ok ? u_row[j] + ub : OOB);
     };
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const f32x4(&v)[TM], const f32x4(&u)[TN]) {
+    auto compute = [&](const f32x4(&v)[TM], const f32x4(&u)[TN], auto nk) {
+        constexpr int NK = decltype(nk)::value;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NK; ++t)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -512,146 +420,102 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][t], v[i][t], acc[j][i], 0, 0, 0);
 #endif
     };
-    const bool co4 = (Co & 3) == 0;
     auto finish = [&](int p) {                          // transform point finished: store and clear
 #if DECNET_WINO_ABLATE == 1 || DECNET_WINO_ABLATE == 5
-        const int pb = OOB - 0x1000000;
+        const int pb = OOB - 0x10000000;
 #else
-        const int pb = (xi0 + p) * m_point;
+        const int pb = (xi0 + p) * m_point + kq * 16;
 #endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int co = wn * (W_BN / 2) + j * 16 + 4 * kq;
+            const int cg = wn * TN + j;                 // 16-co group: rows 4kq + r of MFMA tile j
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int base = m_off[i] != OOB ? m_off[i] + pb + j * 64 : OOB;
-                if (co4) {
-                    const f32x4 a = acc[j][i];
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        i32x4{__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])},
-                        mr, co < Co ? base : OOB, 0, 0);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[j][i][r]), mr,
-                                                              base != OOB && co + r < Co ? base + 4 * r : OOB, 0, 0);
-                }
+                const f32x4 a = acc[j][i];
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    i32x4{__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])},
+                    mr, cg < CG && v_row[i] != OOB ? v_row[i] + pb + cg * v_chunk : OOB, 0, 0);
                 acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
+    using K4 = std::integral_constant<int, 4>;
     // two register sets: the next chunk is in flight while the current one is multiplied, and the
-    // chunk sequence runs across the xg points of this workgroup without draining
-    load(v0, u0, 0, 0);
-    if constexpr (NCH > 0) {
-        static_assert(NCH % 2 == 0, "set parity must repeat per point");
+    // chunk sequence runs across the xg points of this workgroup without draining.
+    // sched_barrier: keep the loads ABOVE the MFMA block they overlap with (the machine scheduler
+    // otherwise sinks each load to just before its first use).
+    load(v0, u0, 0, 0, K4{});
+    if constexpr (NFULL > 0) {
+        constexpr int NS = NFULL + (TAIL > 0);
+        static_assert(NS % 2 == 0, "register set parity must repeat per point");
+        using KT = std::integral_constant<int, (TAIL > 0 ? TAIL : 4)>;
         for (int p = 0; p < xg; ++p) {
 #pragma unroll
-            for (int c = 0; c < NCH; c += 2) {
-                // sched_barrier: keep the loads ABOVE the MFMA block they overlap with (the machine
-                // scheduler otherwise sinks each load to just before its first use)
-                load(v1, u1, p, c + 1);
+            for (int c = 0; c < NS; c += 2) {
+                if (c + 1 == NS - 1) load(v1, u1, p, c + 1, KT{}); else load(v1, u1, p, c + 1, K4{});
                 __builtin_amdgcn_sched_barrier(0);
-                compute(v0, u0);
+                compute(v0, u0, K4{});
                 __builtin_amdgcn_sched_barrier(0);
-                if (c + 2 < NCH) load(v0, u0, p, c + 2); else load(v0, u0, p + 1, 0);
+                if (c + 2 < NS) load(v0, u0, p, c + 2, K4{}); else load(v0, u0, p + 1, 0, K4{});
                 __builtin_amdgcn_sched_barrier(0);
-                compute(v1, u1);
+                if (c + 1 == NS - 1) compute(v1, u1, KT{}); else compute(v1, u1, K4{});
                 __builtin_amdgcn_sched_barrier(0);
             }
             finish(p);
         }
     } else {
+        const int nch = KC, nstep = xg * nch;
         int p = 0, c = 0;                               // step being LOADED
         auto advance = [&]() { if (++c == nch) { c = 0; ++p; } };
         advance();
         int cc = 0, pc = 0;                             // step being COMPUTED
-        const int nstep = xg * nch;
         for (int s = 0; s < nstep; s += 2) {
-            load(v1, u1, p, c); advance();
+            load(v1, u1, p, c, K4{}); advance();
             __builtin_amdgcn_sched_barrier(0);
-            compute(v0, u0);
+            compute(v0, u0, K4{});
             __builtin_amdgcn_sched_barrier(0);
             if (++cc == nch) { finish(pc); cc = 0; ++pc; }
             if (s + 1 >= nstep) break;
-            load(v0, u0, p, c); advance();
+            load(v0, u0, p, c, K4{}); advance();
             __builtin_amdgcn_sched_barrier(0);
-            compute(v1, u1);
+            compute(v1, u1, K4{});
             __builtin_amdgcn_sched_barrier(0);
             if (++cc == nch) { finish(pc); cc = 0; ++pc; }
         }
     }
 }
 
-static int gemm_kind() {          // 0: LDS-staged wino_gemm, 1: register-direct wino_gemm_reg
-    static const int k = [] { const char *e = getenv("DECNET_WINO_GEMM"); return e && !strcmp(e, "lds") ? 0 : 1; }();
-    return k;
-}
-
 template <int WM>
-int launch_gemm_reg(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
-                    hipStream_t stream) {
-    const int mblocks = ceil_div(nt, WM * 48);
-    static const int xg_env = [] { const char *e = getenv("DECNET_WINO_XG"); return e ? atoi(e) : 0; }();
-    int xg = 1;
-    if (xg_env > 0 && np % xg_env == 0) xg = xg_env;
-    static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
-    if ((Ci + 15) / 16 == 14)
-        hipLaunchKernelGGL((wino_gemm_reg<WM, 14>), dim3(mblocks, np / xg), dim3(WM * 128), 0, stream, V, U, M,
-                           nt, Ci, Co, xg, np, swz);
-    else
-        hipLaunchKernelGGL((wino_gemm_reg<WM, 0>), dim3(mblocks, np / xg), dim3(WM * 128), 0, stream, V, U, M,
-                           nt, Ci, Co, xg, np, swz);
-    return decnet_launch_status();
-}
-
-template <int WM, int BK>
 int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                 hipStream_t stream) {
-    constexpr int BM = WM * 48;
-    const size_t lds = 4 * (size_t)(2 * BM * (BK + 2) + 2 * BK * WB_PITCH);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)wino_gemm<WM, BK>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    // transform points per workgroup (a divisor of np): fill whole rounds of the 256 CUs, and
-    // prefer more points per workgroup (one pipeline fill amortised over more K chunks)
-    const int mblocks = ceil_div(nt, BM);
-    int xg = 1;
-    double best = -1.0;
-    for (int c = 1; c <= np; ++c) {
-        if (np % c) continue;
-        const long blocks = (long)mblocks * (np / c);
-        const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256) * (1.0 - 0.12 / c);
-        if (eff > best + 1e-9) { best = eff; xg = c; }
-    }
+    const int mblocks = ceil_div(nt, WM * 48);
     static const int xg_env = [] { const char *e = getenv("DECNET_WINO_XG"); return e ? atoi(e) : 0; }();
+    int xg = 1;                                         // points per workgroup (experiments: 1 is best)
     if (xg_env > 0 && np % xg_env == 0) xg = xg_env;
     static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL((wino_gemm<WM, BK>), dim3(mblocks, np / xg), dim3(WM * 128), lds, stream, V, U, M,
-                       nt, Ci, Co, xg, np, swz);
+    const dim3 grid(mblocks, np / xg), block(WM * 128);
+    if (Ci == 216)
+        hipLaunchKernelGGL((wino_gemm<WM, 13, 2>), grid, block, 0, stream, V, U, M, nt, Ci, Co, xg, np, swz);
+    else
+        hipLaunchKernelGGL((wino_gemm<WM, 0, 0>), grid, block, 0, stream, V, U, M, nt, Ci, Co, xg, np, swz);
     return decnet_launch_status();
 }
 
 int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                   hipStream_t s) {
     static const int tile_env = [] { const char *e = getenv("DECNET_WINO_TILE"); return e ? atoi(e) : 0; }();
-    if (gemm_kind() == 1)
-        return tile_env == 96 ? launch_gemm_reg<2>(V, U, M, nt, Ci, Co, np, s)
-                              : launch_gemm_reg<4>(V, U, M, nt, Ci, Co, np, s);
-    if (tile_env == 96 || !(Ci % 36 == 0 && (long)ceil_div(nt, 192) * np >= 256))
-        return launch_gemm<2, 24>(V, U, M, nt, Ci, Co, np, s);
-    return launch_gemm<4, 36>(V, U, M, nt, Ci, Co, np, s);
+    return tile_env == 192 ? launch_gemm<4>(V, U, M, nt, Ci, Co, np, s) : launch_gemm<2>(V, U, M, nt, Ci, Co, np, s);
 }
 
-// tiles per chunk: V + M of one chunk (2 * np * nt * C floats) <= DECNET_WINO_CHUNK_MB (1 GiB); equal chunks
+__host__ __device__ constexpr int pad16(int c) { return (c + 15) & ~15; }
+
+// tiles per chunk: V + M of one chunk <= DECNET_WINO_CHUNK_MB (1 GiB); equal chunks
 int chunk_tiles(int T, int C, int np) {
     static const double cap_mb = [] {
         const char *e = getenv("DECNET_WINO_CHUNK_MB");       // experiments: V+M bytes per chunk
         return e ? atof(e) : 1024.0;
     }();
-    long cap = (long)(cap_mb * 1024 * 1024 / (2.0 * np * 4 * C));
+    long cap = (long)(cap_mb * 1024 * 1024 / (2.0 * np * 4 * pad16(C)));
     if (cap < 192) cap = 192;
     const long nchunks = (T + cap - 1) / cap;          // equal chunks
     return (int)((T + nchunks - 1) / nchunks);
@@ -667,19 +531,20 @@ int conv_variant(const float *x, const float *u, const float *scale, const float
     if (Td >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
     const int T = (int)Td, cmax = Ci > Co ? Ci : Co;
     const int ct = chunk_tiles(T, cmax, NP);
-    if ((double)ct * cmax * 4 * NP >= 2147483647.0) return DECNET_ERR_UNSUPPORTED;   // 32-bit offsets
-    float *V = workspace, *M = workspace + (size_t)NP * ct * Ci;
+    if ((double)ct * pad16(cmax) * 4 * NP >= 2147483647.0) return DECNET_ERR_UNSUPPORTED;   // 32-bit offsets
+    float *V = workspace, *M = workspace + (size_t)NP * ct * pad16(Ci);
     for (int t_lo = 0; t_lo < T; t_lo += ct) {
         const int nt = T - t_lo < ct ? T - t_lo : ct;
-        size_t n = (size_t)nt * Ci;
+        size_t n = (size_t)nt * pad16(Ci);
         hipLaunchKernelGGL((wino_input_transform<TD, TH, TW>), dim3((unsigned)((n + 255) / 256)), dim3(256),
-                           0, s, x, V, g, Ci, t_lo, nt);
+                           0, s, x, V, g, Ci, t_lo, nt, (int)((size_t)B * D * H * W * Ci * 4));
         int rc = decnet_launch_status();
         if (rc) return rc;
         if ((rc = gemm_dispatch(V, u, M, nt, Ci, Co, NP, s))) return rc;
-        n = (size_t)nt * Co;
+        n = (size_t)nt * pad16(Co);
         hipLaunchKernelGGL((wino_output_transform<TD, TH, TW>), dim3((unsigned)((n + 255) / 256)), dim3(256),
-                           0, s, M, scale, shift, residual, y, g, Co, relu, t_lo, nt);
+                           0, s, M, scale, shift, residual, y, g, Co, relu, t_lo, nt,
+                           (int)((size_t)B * D * H * W * Co * 4));
         if ((rc = decnet_launch_status())) return rc;
     }
     return DECNET_OK;
@@ -694,7 +559,7 @@ extern "C" {
 /* variant: 0 = F(2,3)^3 (64 transform points), 1 = F(2,3) on D x F(4,3) on H, W (144 points) */
 size_t decnet_conv3d_wino_weight_floats(int Ci, int variant) {
     const int np = variant_points(variant);
-    return np < 0 || Ci < 1 ? 0 : (size_t)np * Ci * W_BN;
+    return np < 0 || Ci < 1 ? 0 : (size_t)np * pad16(Ci) * W_BN;
 }
 
 int decnet_conv3d_wino_pack_weight(const float *w, float *u, int Co, int Ci, int variant, void *stream) {
@@ -704,21 +569,22 @@ int decnet_conv3d_wino_pack_weight(const float *w, float *u, int Co, int Ci, int
     const int n = Ci * W_BN;
     if (variant == 0)
         hipLaunchKernelGGL((wino_weight_transform<4, 4, 4>), dim3(ceil_div(n, 128)), dim3(128), 0,
-                           (hipStream_t)stream, w, u, Co, Ci, gemm_kind());
+                           (hipStream_t)stream, w, u, Co, Ci);
     else
         hipLaunchKernelGGL((wino_weight_transform<4, 6, 6>), dim3(ceil_div(n, 128)), dim3(128), 0,
-                           (hipStream_t)stream, w, u, Co, Ci, gemm_kind());
+                           (hipStream_t)stream, w, u, Co, Ci);
     return decnet_launch_status();
 }
 
-/* The batched GEMM stage alone (measurement / composition): M[xi] = V[xi] * U[xi], xi < np points,
- * V [np][nt][Ci], U from decnet_conv3d_wino_pack_weight, M [np][nt][Co]. */
+/* The batched GEMM stage alone (measurement / composition): M[xi] = V[xi] * U[xi], xi < points;
+ * V [points][ceil(Ci/16)][nt][16], u from decnet_conv3d_wino_pack_weight,
+ * M [points][ceil(Co/16)][nt][16]. */
 int decnet_conv3d_wino_gemm(const float *V, const float *u, float *M, int nt, int Ci, int Co,
                             int variant, void *stream) {
     const int np = variant_points(variant);
     if (!V || !u || !M) return DECNET_ERR_NULL_POINTER;
     if (nt < 1 || Ci < 1 || Co < 1 || np < 0) return DECNET_ERR_BAD_SHAPE;
-    if (Ci % 4 != 0 || Co > W_BN || (double)nt * (Ci > Co ? Ci : Co) * 4 * np >= 2147483647.0)
+    if (Ci % 4 != 0 || Co > W_BN || (double)nt * pad16(Ci > Co ? Ci : Co) * 4 * np >= 2147483647.0)
         return DECNET_ERR_UNSUPPORTED;
     return gemm_dispatch(V, u, M, nt, Ci, Co, np, (hipStream_t)stream);
 }
@@ -730,7 +596,7 @@ size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, i
     const double T = (double)B * ((D + 1) / 2) * ((H + oh - 1) / oh) * ((W + oh - 1) / oh);
     if (T >= 2147483648.0) return 0;
     const int nt = chunk_tiles((int)T, Ci > Co ? Ci : Co, np);
-    return (size_t)np * nt * ((size_t)Ci + Co);
+    return (size_t)np * nt * ((size_t)pad16(Ci) + pad16(Co));
 }
 
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale, const float *shift,
@@ -740,7 +606,7 @@ int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale
     if (B < 1 || D < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1 || variant_points(variant) < 0)
         return DECNET_ERR_BAD_SHAPE;
     if (Ci % 4 != 0 || Co > W_BN) return DECNET_ERR_UNSUPPORTED;
-    if ((double)B * D * H * W * (Ci > Co ? Ci : Co) >= 2147483648.0 * 4) return DECNET_ERR_BAD_SHAPE;
+    if ((double)B * D * H * W * (Ci > Co ? Ci : Co) * 4 >= 2147483647.0) return DECNET_ERR_UNSUPPORTED;  // 32-bit offsets
     hipStream_t s = (hipStream_t)stream;
     if (variant == 0)
         return conv_variant<2, 2, 2>(x, u, scale, shift, residual, y, workspace, B, D, H, W, Ci, Co, relu, s);

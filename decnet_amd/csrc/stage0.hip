@@ -55,34 +55,56 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
     const float wy1 = iy - fy, wy0 = 1.0f - wy1;
     const size_t plane = (size_t)H * W;
     const float *Lb = left + (size_t)b * C * plane, *Rb = right + (size_t)b * C * plane;
-    for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
-        int c = i / W, x = i - c * W;
-        Ls[c * WP + x] = Lb[c * plane + (size_t)y * W + x];
-        R0[c * WP + x] = (y0 >= 0 && y0 < H) ? Rb[c * plane + (size_t)y0 * W + x] : 0.f;
-        R1[c * WP + x] = (y1 >= 0 && y1 < H) ? Rb[c * plane + (size_t)y1 * W + x] : 0.f;
-    }
+    // no per-element integer division anywhere: a wave stages one channel row at a time, and later
+    // owns one (d, x) output column at a time with its lanes across the channels
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    constexpr int U = 9;                       // channel rows in flight per wave (latency, not bandwidth, bounds this)
+    for (int x = lane; x < W; x += 64)
+        for (int c0 = wave; c0 < C; c0 += nwaves * U) {
+            float l[U], r0[U], r1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * nwaves;
+                const bool ok = c < C;
+                l[u] = ok ? Lb[c * plane + (size_t)y * W + x] : 0.f;
+                r0[u] = ok && vy0 ? Rb[c * plane + (size_t)y0 * W + x] : 0.f;
+                r1[u] = ok && vy1 ? Rb[c * plane + (size_t)y1 * W + x] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * nwaves;
+                if (c < C) {
+                    Ls[c * WP + x] = l[u];
+                    R0[c * WP + x] = r0[u];
+                    R1[c * WP + x] = r1[u];
+                }
+            }
+        }
     __syncthreads();
     // blockIdx.y picks a chunk of disparities (more workgroups than the B*H rows alone)
     const int d_lo = blockIdx.y * dchunk, d_hi = min(D, d_lo + dchunk);
-    const int n = (d_hi - d_lo) * W * C;
     float *out = cost + (size_t)b * D * plane * C + (size_t)y * W * C;     // + d*plane*C + x*C + c
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int c = i % C, t = i / C;
-        int x = t % W, d = d_lo + t / W;
-        float l = x >= d ? Ls[c * WP + x] : 0.f;                  // submodule.py:506-508
+    for (int t = d_lo * W + wave; t < d_hi * W; t += nwaves) {
+        const int d = t / W, x = t - d * W;                       // wave-uniform
         float cx = (float)(x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
         float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f;
         float fx = floorf(ix);
         int x0 = (int)fx, x1 = x0 + 1;
         float wx1 = ix - fx, wx0 = 1.0f - wx1;
         bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
-        bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
-        float r = 0.f;                                            // same tap order as grid_sample
-        if (vy0 && vx0) r += R0[c * WP + x0] * (wx0 * wy0);
-        if (vy0 && vx1) r += R0[c * WP + x1] * (wx1 * wy0);
-        if (vy1 && vx0) r += R1[c * WP + x0] * (wx0 * wy1);
-        if (vy1 && vx1) r += R1[c * WP + x1] * (wx1 * wy1);
-        out[(size_t)d * plane * C + (size_t)x * C + c] = l * r;   // submodule.py:521
+        const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+        float *o = out + (size_t)d * plane * C + (size_t)x * C;
+        for (int c = lane; c < C; c += 64) {
+            float l = x >= d ? Ls[c * WP + x] : 0.f;              // submodule.py:506-508
+            float r = 0.f;                                        // same tap order as grid_sample
+            if (vy0 && vx0) r += R0[c * WP + x0] * w00;
+            if (vy0 && vx1) r += R0[c * WP + x1] * w01;
+            if (vy1 && vx0) r += R1[c * WP + x0] * w10;
+            if (vy1 && vx1) r += R1[c * WP + x1] * w11;
+            o[c] = l * r;                                         // submodule.py:521
+        }
     }
 }
 
@@ -594,6 +616,102 @@ int launch_conv_dma(const float *x, const float *wp, const float *scale, const f
     return decnet_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Last Conv3dUnit (Ci -> 1) in two passes that read the activations ONCE (the one-kernel version
+// above gathers every input row 27 times):
+//   1. cout1_tap_gemm: T[p][tap] = sum_c x[p][c] * w[tap][c] for every input position p -- a
+//      [M x Ci] x [Ci x 27] GEMM on the matrix cores (taps padded to 32 = two 16-row MFMA tiles),
+//      operands straight from memory to registers with the K-permuted 16-byte-per-lane loads of
+//      conv3d_winograd.hip:wino_gemm; the 27 x Ci weights stay in registers.
+//   2. cout1_gather_softargmax: cost[d,y,x] = sum_tap T[p + offset(tap)][tap] over the taps inside
+//      the volume (T is 32 floats per position: L2 resident), BN scale/shift, then the running
+//      softmax expectation over d exactly as conv3d_cout1_softargmax.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+template <int KC>      // chunks of 16 channels, Ci <= 16*KC
+__global__ __launch_bounds__(256) void cout1_tap_gemm(const float *__restrict__ x,
+                                                      const float *__restrict__ w,
+                                                      float *__restrict__ T, int M, int Ci,
+                                                      int x_bytes) {
+    constexpr int OOB = 0x7fffffff;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    // A operand: weights, row = tap (two tiles of 16), lane's k = 16c + 4kq + {0..3}
+    f32x4_t wv[2][KC];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tap = t * 16 + i16, k = c * 16 + kq * 4 + e;
+                wv[t][c][e] = tap < 27 && k < Ci ? w[(size_t)k * 27 + tap] : 0.f;
+            }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    for (int g = wave; g * 16 < M; g += nwaves) {
+        const int p = g * 16 + i16;
+        f32x4_t xv[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = c * 16 + kq * 4;
+            const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, p < M && k < Ci ? (p * Ci + k) * 4 : OOB, 0, 0);
+            xv[c] = f32x4_t{__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)};
+        }
+        f32x4_t acc[2][2] = {};                         // [tap tile][k parity]: four independent chains
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[t][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][c][e], xv[c][e], acc[t][e & 1], 0, 0, 0);
+        if (p < M) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)                 // rows 4kq + r of tile t = taps, column = position
+                *reinterpret_cast<f32x4_t *>(T + (size_t)p * 32 + t * 16 + kq * 4) = acc[t][0] + acc[t][1];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cout1_gather_softargmax(const float *__restrict__ T, float scale,
+                                                               float shift, float *__restrict__ reg,
+                                                               float *__restrict__ pred, int B, int D,
+                                                               int H, int W, int PB) {
+    extern __shared__ float costs[];                   // [PB][D]
+    const int npix = B * H * W;
+    const int pl = threadIdx.x / D, d = threadIdx.x - pl * D;
+    const int pix = blockIdx.x * PB + pl;
+    if (pl < PB && pix < npix) {
+        const int xx = pix % W, t = pix / W;
+        const int yy = t % H, b = t / H;
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int zd = d + tap / 9 - 1, zy = yy + (tap / 3) % 3 - 1, zx = xx + tap % 3 - 1;
+            if ((unsigned)zd < (unsigned)D && (unsigned)zy < (unsigned)H && (unsigned)zx < (unsigned)W)
+                acc += T[((((size_t)b * D + zd) * H + zy) * W + zx) * 32 + tap];
+        }
+        const float cost = fmaf(acc, scale, shift);
+        costs[pl * D + d] = cost;
+        if (reg) reg[(((size_t)b * D + d) * H + yy) * W + xx] = cost;
+    }
+    __syncthreads();
+    if (threadIdx.x < PB && blockIdx.x * PB + threadIdx.x < npix) {
+        float m = -INFINITY, S = 0.f, Tt = 0.f;
+        for (int dd = 0; dd < D; ++dd) {
+            const float cost = costs[threadIdx.x * D + dd];
+            const float mn = fmaxf(m, cost);
+            const float r = expf(m - mn), e = expf(cost - mn);       // m = -inf -> r = 0
+            S = fmaf(S, r, e);
+            Tt = fmaf(Tt, r, e * (float)dd);
+            m = mn;
+        }
+        pred[blockIdx.x * PB + threadIdx.x] = Tt / S;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -688,6 +806,38 @@ int decnet_conv3d_cout1_softargmax(const float *x, const float *w, float scale, 
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(conv3d_cout1_softargmax, dim3(blocks), dim3(256), lds, (hipStream_t)stream,
                        x, w, scale, shift, reg, pred, B, D, H, W, Ci);
+    return decnet_launch_status();
+}
+
+/* The same operator in two passes over a workspace of decnet_conv3d_cout1_workspace_floats(B,D,H,W)
+ * floats: the activations are read once instead of 27 times. */
+size_t decnet_conv3d_cout1_workspace_floats(int B, int D, int H, int W) {
+    if (B < 1 || D < 1 || H < 1 || W < 1) return 0;
+    return (size_t)B * D * H * W * 32;
+}
+
+int decnet_conv3d_cout1_softargmax_ws(const float *x, const float *w, float scale, float shift,
+                                      float *reg, float *pred, float *workspace, int B, int D, int H,
+                                      int W, int Ci, void *stream) {
+    if (!x || !w || !pred || !workspace) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || Ci < 1) return DECNET_ERR_BAD_SHAPE;
+    const double Md = (double)B * D * H * W;
+    if (Ci % 4 != 0 || Ci > 256 || D > 256 || Md * Ci * 4 >= 2147483647.0) return DECNET_ERR_UNSUPPORTED;
+    const int M = (int)Md, x_bytes = (int)(Md * Ci * 4);
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = ceil_div(ceil_div(M, 16), 4);
+    if (blocks > 512) blocks = 512;
+    if (Ci <= 224 && Ci > 128)
+        hipLaunchKernelGGL((cout1_tap_gemm<14>), dim3(blocks), dim3(256), 0, s, x, w, workspace, M, Ci, x_bytes);
+    else if (Ci <= 128)
+        hipLaunchKernelGGL((cout1_tap_gemm<8>), dim3(blocks), dim3(256), 0, s, x, w, workspace, M, Ci, x_bytes);
+    else
+        hipLaunchKernelGGL((cout1_tap_gemm<16>), dim3(blocks), dim3(256), 0, s, x, w, workspace, M, Ci, x_bytes);
+    int rc = decnet_launch_status();
+    if (rc) return rc;
+    const int PB = 256 / D, npix = B * H * W;
+    hipLaunchKernelGGL(cout1_gather_softargmax, dim3(ceil_div(npix, PB)), dim3(256), (size_t)PB * D * 4, s,
+                       workspace, scale, shift, reg, pred, B, D, H, W, PB);
     return decnet_launch_status();
 }
 

@@ -31,7 +31,7 @@ def conv_algo():
     """"winograd" (default: F(2,3) on D,H,W, 3.4x fewer multiplications), "winograd4" (F(2,3) on D,
     F(4,3) on H and W, 6x fewer) or "direct" (27-tap implicit GEMM); DECNET_CONV_ALGO overrides.
     All are fp32 on the matrix cores; they differ by fp32 rounding only (~1e-6 / ~6e-6 relative)."""
-    a = os.environ.get("DECNET_CONV_ALGO", "winograd").lower()
+    a = os.environ.get("DECNET_CONV_ALGO", "winograd4").lower()
     if a not in ("winograd", "winograd4", "direct"):
         raise ValueError("DECNET_CONV_ALGO must be 'winograd', 'winograd4' or 'direct'")
     return a
@@ -224,6 +224,13 @@ class CostRegNetNoDown(nn.Module):
             self._ws[dev] = ws
         return ws
 
+    def _scratch(self, dev, n):
+        t = self._ws.get(("scratch", dev))
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.float32, device=dev)
+            self._ws[("scratch", dev)] = t
+        return t
+
     def run_ndhwc(self, x, want_reg=True, want_pred=True):
         """x: channels-last cost volume [B,D,H,W,C].  Returns (reg [B,D,H,W] or None,
         pred [B,H,W] or None).  The input buffer is not modified."""
@@ -280,10 +287,18 @@ class CostRegNetNoDown(nn.Module):
             conv(5, a, b)
             conv(6, b, c)
             p = P[7]
-            rc = L.decnet_conv3d_cout1_softargmax(
-                c.data_ptr(), p["w"].data_ptr(), p["scale"], p["shift"],
-                reg.data_ptr() if reg is not None else None, pred.data_ptr(), B, D, H, W, p["Ci"], st)
-            _lib.check(rc, "decnet_conv3d_cout1_softargmax")
+            regp = reg.data_ptr() if reg is not None else None
+            need = L.decnet_conv3d_cout1_workspace_floats(B, D, H, W)
+            if p["Ci"] <= 256 and D <= 256 and os.environ.get("DECNET_COUT1", "gemm") != "gather":
+                t = a if a.numel() >= need else self._scratch(dev, need)     # a is free by now
+                rc = L.decnet_conv3d_cout1_softargmax_ws(c.data_ptr(), p["w"].data_ptr(), p["scale"], p["shift"],
+                                                         regp, pred.data_ptr(), t.data_ptr(), B, D, H, W,
+                                                         p["Ci"], st)
+                _lib.check(rc, "decnet_conv3d_cout1_softargmax_ws")
+            else:
+                rc = L.decnet_conv3d_cout1_softargmax(c.data_ptr(), p["w"].data_ptr(), p["scale"], p["shift"],
+                                                      regp, pred.data_ptr(), B, D, H, W, p["Ci"], st)
+                _lib.check(rc, "decnet_conv3d_cout1_softargmax")
         return reg, (pred if want_pred else None)
 
     def forward(self, x):

@@ -123,15 +123,17 @@ int decnet_conv3d_bn_act(const float *x, const float *w_packed, const float *sca
  * instead of 27, ~1e-6 relative;  variant 1: F(2,3) on D, F(4,3) on H and W -- 144 points, 4.5
  * multiplies per output, ~6e-6 relative.
  *   u          weights transformed once by decnet_conv3d_wino_pack_weight:
- *              [Co,Ci,3,3,3] -> [points, Ci, 224]  (decnet_conv3d_wino_weight_floats floats)
+ *              [Co,Ci,3,3,3] -> U^T [points][ceil(Ci/16)][224][16]
+ *              (decnet_conv3d_wino_weight_floats floats)
  *   workspace  decnet_conv3d_wino_workspace_floats(...) floats of device scratch
  *   everything else as decnet_conv3d_bn_act.                                                */
 size_t decnet_conv3d_wino_weight_floats(int Ci, int variant);
 int decnet_conv3d_wino_pack_weight(const float *w_oidhw, float *u, int Co, int Ci, int variant,
                                    void *stream);
 size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co, int variant);
-/* its GEMM stage alone: M[xi] = V[xi] * U[xi] for every transform point xi;
- * V [points][nt][Ci] (transformed input tiles), M [points][nt][Co]. */
+/* its GEMM stage alone: M[xi] = V[xi] * U[xi] for every transform point xi, 16 channels (64 bytes)
+ * being the unit of all three layouts:
+ *   V [points][ceil(Ci/16)][nt][16] (transformed input tiles), M [points][ceil(Co/16)][nt][16]. */
 int decnet_conv3d_wino_gemm(const float *V, const float *u, float *M, int nt, int Ci, int Co,
                             int variant, void *stream);
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale,
@@ -147,6 +149,14 @@ int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale
 int decnet_conv3d_cout1_softargmax(const float *x, const float *w_oidhw, float scale,
                                    float shift, float *reg, float *pred, int B, int D, int H,
                                    int W, int Ci, void *stream);
+
+/* The same operator in two passes (a [positions x Ci] x [Ci x 27] product on the matrix cores, then
+ * a 27-tap gather + soft-argmax) that read x once instead of 27 times.  workspace:
+ * decnet_conv3d_cout1_workspace_floats(B,D,H,W) floats of device scratch.  Ci <= 256, D <= 256. */
+size_t decnet_conv3d_cout1_workspace_floats(int B, int D, int H, int W);
+int decnet_conv3d_cout1_softargmax_ws(const float *x, const float *w_oidhw, float scale,
+                                      float shift, float *reg, float *pred, float *workspace,
+                                      int B, int D, int H, int W, int Ci, void *stream);
 
 /* disparity_regression for arbitrary samples (submodule.py:766-777):
  *   cost, samples [B,S,H,W] -> pred [B,H,W]                                                */

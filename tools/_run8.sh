@@ -1,0 +1,12 @@
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01e -o r01e -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/bench_r01e_prof.json 2> $R/gpurun_out/bench_r01e.err
+cd $R
+find gpurun_out/prof_r01e -name "*kernel_stats*" | head -3
+python3 - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/prof_r01e/**/*kernel_stats.csv',recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+for r in rows[:16]:
+    print("%-80s calls=%s avg_us=%.1f pct=%s" % (r['Name'][:80], r['Calls'], float(r['AverageNs'])/1e3, r['Percentage']))
+PY

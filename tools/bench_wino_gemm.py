@@ -23,7 +23,8 @@ def main():
     C = a.c
     dev = torch.device("cuda:0")
     L = _lib.lib()
-    V = torch.randn(npts * nt * C, device=dev)
+    CP = (C + 15) // 16 * 16
+    V = torch.randn(npts * nt * CP, device=dev)
     U = torch.randn(L.decnet_conv3d_wino_weight_floats(C, a.variant), device=dev)
     if a.data == "zeros":
         V.zero_(), U.zero_()
@@ -32,7 +33,7 @@ def main():
     elif a.data == "small":          # few mantissa bits set
         V = V.to(torch.bfloat16).float()
         U = U.to(torch.bfloat16).float()
-    M = torch.empty(npts * nt * C, device=dev)
+    M = torch.empty(npts * nt * CP, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
