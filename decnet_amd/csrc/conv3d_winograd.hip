@@ -144,22 +144,21 @@ __device__ __forceinline__ void tile_coords(int t, const Tiling &g, int &b, int 
 
 // ------------------------------ input transform -----------------------------------------
 // x [B,D,H,W,C] -> V[xi][c/16][tile - t_lo][c%16], V = B^T d B along D, H, W.  One thread per
-// (16-channel group, tile, channel in group): a wave is 4 tiles x 16 channels.
+// (tile, channel).  Measured alternatives that were not faster: 4 tiles x 16 channels per wave
+// (256-byte V stores, 64-byte x loads), and staging a row of tiles through LDS (phases serialise:
+// two workgroups per CU are not enough to overlap them).
 template <int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void wino_input_transform(const float *__restrict__ x,
                                                             float *__restrict__ V, Tiling g, int C,
                                                             int t_lo, int nt, int x_bytes) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int KC = (C + 15) >> 4;
-#ifdef DECNET_WINO_MAP1
-    const int tl = (int)(idx / (KC * 16)), c = (int)(idx - (size_t)tl * (KC * 16)), kc = c >> 4;
-    if (tl >= nt || c >= C) return;
-#else
-    const size_t q = idx >> 4;
-    const int kc = (int)(q / nt), tl = (int)(q - (size_t)kc * nt);
-    const int c = kc * 16 + (int)(idx & 15);
-    if (kc >= KC || c >= C) return;
-#endif
+    // workgroup = one tile, all channels (a wave = 64 consecutive channels: whole cache lines of x);
+    // XCD aware: ids equal mod 8 (one XCD, one L2) walk a contiguous range of tiles, so the halo
+    // shared by neighbouring tiles and the second half of V's 128-byte lines meet in the same L2
+    const int per_xcd = (nt + 7) >> 3;
+    const int tl = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int c = blockIdx.y * blockDim.x + threadIdx.x, kc = c >> 4;   // blockIdx.y > 0 only if C > 256
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tl >= nt || c >= C) return;
     int b, z0, y0, x0;
     tile_coords<TD - 2, TH - 2, TW - 2>(t_lo + tl, g, b, z0, y0, x0);
     // branch-free halo: out-of-volume taps are sent past the end of the buffer and read as zeros, so
@@ -346,25 +345,13 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, int voff)
     }
 }
 
-template <int WM, int NFULL, int TAIL>
-__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm(
-    const float *__restrict__ Vb, const float *__restrict__ Ub, float *__restrict__ Mb, int nt, int Ci,
-    int Co, int xg, int np, int swz) {
-    constexpr int TM = 3, TN = 7, BM = WM * 48, OOB = 0x7fffffff;
-    // XCD-aware task order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
-    // workgroup ids that are equal mod 8 take the M blocks of the SAME transform points: one XCD's
-    // L2 then holds U of one point group at a time instead of every XCD streaming all of U.
-    const int mblocks = gridDim.x, ngroups = gridDim.y;
-    int pg = blockIdx.y, mb = blockIdx.x;
-    if (swz) {
-        const int id = blockIdx.y * mblocks + blockIdx.x, per8 = 8 * mblocks;
-        const int r = id / per8, q = id - r * per8;
-        if (8 * (r + 1) <= ngroups) { pg = 8 * r + (q & 7); mb = q >> 3; }     // tail (< 8 groups) unswizzled
-    }
-    const int xi0 = pg * xg;                            // this workgroup's xg consecutive points
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, kq = lane >> 4;
-    const int m0 = mb * BM + wm * 48;
+// One wave's work: TM x 7 MFMA tiles (16*TM tiles m from m0, 112 co) of the xg points from xi0.
+template <int NFULL, int TAIL, int TM>
+__device__ __forceinline__ void wino_gemm_wave(const float *__restrict__ Vb, const float *__restrict__ Ub,
+                                               float *__restrict__ Mb, int nt, int Ci, int Co, int xg,
+                                               int np, int xi0, int m0, int wn) {
+    constexpr int TN = 7, OOB = 0x7fffffff;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
     if (m0 >= nt) return;                               // no barriers: idle waves of the M tail just leave
     const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;
     const int v_chunk = nt * 64, u_chunk = W_BN * 64;                 // bytes per 16-channel chunk
@@ -485,15 +472,35 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// Workgroup = WM x 2 waves (WM row groups of 48 tiles x the two halves of co).  (Levelling the last
+// round of workgroups with smaller tail tasks was measured: slower, the dispatcher already fills
+// the gaps.)
+template <int WM, int NFULL, int TAIL>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm(
+    const float *__restrict__ Vb, const float *__restrict__ Ub, float *__restrict__ Mb, int nt, int Ci,
+    int Co, int xg, int np, int swz) {
+    // XCD-aware task order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+    // workgroup ids that are equal mod 8 take the M blocks of the SAME transform points: one XCD's
+    // L2 then holds U of one point group at a time instead of every XCD streaming all of U.
+    const int mblocks = gridDim.x, ngroups = gridDim.y;
+    int pg = blockIdx.y, mb = blockIdx.x;
+    if (swz) {
+        const int id = blockIdx.y * mblocks + blockIdx.x, per8 = 8 * mblocks;
+        const int r = id / per8, q = id - r * per8;
+        if (8 * (r + 1) <= ngroups) { pg = 8 * r + (q & 7); mb = q >> 3; }     // tail (< 8 groups) unswizzled
+    }
+    const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    wino_gemm_wave<NFULL, TAIL, 3>(Vb, Ub, Mb, nt, Ci, Co, xg, np, pg * xg, (mb * WM + wm) * 48, wn);
+}
+
 template <int WM>
 int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                 hipStream_t stream) {
-    const int mblocks = ceil_div(nt, WM * 48);
     static const int xg_env = [] { const char *e = getenv("DECNET_WINO_XG"); return e ? atoi(e) : 0; }();
     int xg = 1;                                         // points per workgroup (experiments: 1 is best)
     if (xg_env > 0 && np % xg_env == 0) xg = xg_env;
     static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
-    const dim3 grid(mblocks, np / xg), block(WM * 128);
+    const dim3 grid(ceil_div(nt, WM * 48), np / xg), block(WM * 128);
     if (Ci == 216)
         hipLaunchKernelGGL((wino_gemm<WM, 13, 2>), grid, block, 0, stream, V, U, M, nt, Ci, Co, xg, np, swz);
     else
@@ -504,7 +511,9 @@ int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co
 int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                   hipStream_t s) {
     static const int tile_env = [] { const char *e = getenv("DECNET_WINO_TILE"); return e ? atoi(e) : 0; }();
-    return tile_env == 192 ? launch_gemm<4>(V, U, M, nt, Ci, Co, np, s) : launch_gemm<2>(V, U, M, nt, Ci, Co, np, s);
+    return tile_env == 192 ? launch_gemm<4>(V, U, M, nt, Ci, Co, np, s)
+         : tile_env == 48 ? launch_gemm<1>(V, U, M, nt, Ci, Co, np, s)
+                          : launch_gemm<2>(V, U, M, nt, Ci, Co, np, s);
 }
 
 __host__ __device__ constexpr int pad16(int c) { return (c + 15) & ~15; }
@@ -535,13 +544,15 @@ int conv_variant(const float *x, const float *u, const float *scale, const float
     float *V = workspace, *M = workspace + (size_t)NP * ct * pad16(Ci);
     for (int t_lo = 0; t_lo < T; t_lo += ct) {
         const int nt = T - t_lo < ct ? T - t_lo : ct;
-        size_t n = (size_t)nt * pad16(Ci);
-        hipLaunchKernelGGL((wino_input_transform<TD, TH, TW>), dim3((unsigned)((n + 255) / 256)), dim3(256),
-                           0, s, x, V, g, Ci, t_lo, nt, (int)((size_t)B * D * H * W * Ci * 4));
+        const int x_bytes = (int)((size_t)B * D * H * W * Ci * 4);
+        const int ith = Ci >= 256 ? 256 : (Ci + 63) / 64 * 64;
+        hipLaunchKernelGGL((wino_input_transform<TD, TH, TW>),
+                           dim3((unsigned)(8 * ((nt + 7) / 8)), (unsigned)ceil_div(Ci, ith)), dim3(ith), 0, s, x, V,
+                           g, Ci, t_lo, nt, x_bytes);
         int rc = decnet_launch_status();
         if (rc) return rc;
         if ((rc = gemm_dispatch(V, u, M, nt, Ci, Co, NP, s))) return rc;
-        n = (size_t)nt * pad16(Co);
+        const size_t n = (size_t)nt * pad16(Co);
         hipLaunchKernelGGL((wino_output_transform<TD, TH, TW>), dim3((unsigned)((n + 255) / 256)), dim3(256),
                            0, s, M, scale, shift, residual, y, g, Co, relu, t_lo, nt,
                            (int)((size_t)B * D * H * W * Co * 4));
