@@ -24,11 +24,15 @@
 //              left pixels against 16-wide tiles of the COMPACTED list of active right pixels
 //              in the window, so work scales with density^2 and the pass becomes HBM-bound.
 //   Both paths then run max / exp-sum / variance passes over registers and a 4-lane exchange.
+// Rows with at most 256 active pixels per side are taken by spamat_fwd_sparse (further down) before
+// this kernel runs: it never stages a whole row and reaches 55-93 % of the HBM roofline.
 //
 // <= 128 VGPRs: 4 waves share a SIMD (fp32 MFMA and VALU share the FP32 units on gfx950 --
 // measured, see DESIGN.md -- so occupancy hides latency, it does not add throughput).
 // Compiled with -fno-honor-nans (build.py): otherwise every fmaxf on an MFMA result costs an
 // extra canonicalising v_max.
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifndef DECNET_ABLATE
@@ -233,7 +237,10 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int segs_per_row, int XT, int allow_compact) {
+    int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker) {
+    // marker: this launch follows spamat_fwd_sparse, which left -1 in sum_sim[row start] of exactly
+    // the rows it did not take (a real sum_similarities is never negative)
+    if (marker && sum_sim[(size_t)blockIdx.x * W] != -1.0f) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Layout lo = make_layout(C, NT, XT);
     float *Rs = smem + lo.offR;
@@ -532,6 +539,178 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse rows (<= 256 active pixels on each side, i.e. up to ~26 % density at stage 3): nothing but
+// the masks and the features of the ACTIVE pixels is touched.  The kernel above stages the whole
+// right row (39 KB of LDS at stage 3: two workgroups per CU) and then makes a second, dependent
+// round trip for the left features, so a CU never has more than ~1 row of HBM traffic in flight,
+// well short of the ~90 KB that 8 TB/s x latency needs; here a row costs 256 threads, <= 128 VGPRs
+// and ~28 KB of LDS (compacted index lists + compacted feature tiles), four workgroups per CU.
+//   1. both mask rows -> activity bits, block-wide exclusive counts (RK / RKL) and index lists
+//   2. gather the C features of the active right / left pixels into RF / LF [C][slot] (all loads of
+//      a thread in flight together), zero-fill the outputs of inactive left pixels meanwhile
+//   3. spans of S left pixels x 16-wide tiles of the compacted right list: MFMA cost tiles and the
+//      softmax passes of the compact path above (d from the index lists)
+// Rows that are not sparse enough are left to spamat_fwd_mfma, launched right after with
+// marker = 1: this kernel writes -1 to sum_sim[row start] of exactly those rows.
+constexpr int SP_THREADS = 256, SP_NWAVE = SP_THREADS / 64, SP_CAP = 256, SP_FP = SP_CAP + 16;
+
+template <int NT, int MODE, int KQ>
+__global__ __launch_bounds__(SP_THREADS, 6) void spamat_fwd_sparse(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
+    float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
+    int H, int W, int D) {
+    // at most 8 cost tiles per span (32 accumulator registers: six workgroups per CU); a row whose
+    // disparity windows hold more than 8*16-15 active right pixels even for 16-pixel spans goes to
+    // spamat_fwd_mfma like the dense ones
+    constexpr int CQ = 4 * KQ, NTC = NT + 1 < 8 ? NT + 1 : 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // words: XR [CAP+16] | RK [1028 x u16] | RKL [1028 x u16] | XL [CAP] | WT [16] | RF [CQ][FP] | LF [CQ][FP]
+    constexpr int offXR = 0, offRK = SP_CAP + 16, offRKL = offRK + 514, offXL = offRKL + 514,
+                  offWT = offXL + SP_CAP, offRF = offWT + 16, offLF = offRF + CQ * SP_FP;
+    int *XR = reinterpret_cast<int *>(smem) + offXR;
+    unsigned short *RK = reinterpret_cast<unsigned short *>(smem + offRK);
+    unsigned short *RKL = reinterpret_cast<unsigned short *>(smem + offRKL);
+    int *XL = reinterpret_cast<int *>(smem) + offXL;
+    int *WT = reinterpret_cast<int *>(smem) + offWT;
+    float *RF = smem + offRF, *LF = smem + offLF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, b = row / H, y = row - b * H;
+    const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
+    const float *lrow = ref + ((size_t)b * C * H + y) * W;
+    const float *rrow = tar + ((size_t)b * C * H + y) * W;
+    const float *trow = tmask + rowpix, *mrow = rmask + rowpix;
+
+    // ---- 1. masks -> bits, counts
+    const int p4 = tid * 4;
+    int fr = 0, fl = 0;
+    {
+        const bool alm = ((W & 3) == 0) && ((((uintptr_t)trow) | ((uintptr_t)mrow)) & 15) == 0;
+        if (p4 < W) {
+            const float4 tv = load4(trow, p4, W, alm), mv = load4(mrow, p4, W, alm);
+            fr = (tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3);
+            fl = (mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3);
+        }
+    }
+    const int cr = __popc(fr), cl = __popc(fl);
+    const int ir = wave_incl_scan(cr, lane), il = wave_incl_scan(cl, lane);
+    if (lane == 63) { WT[wave] = ir; WT[4 + wave] = il; }
+    __syncthreads();
+    int nR = 0, nL = 0, baseR = 0, baseL = 0;
+#pragma unroll
+    for (int w = 0; w < SP_NWAVE; ++w) {
+        if (w < wave) { baseR += WT[w]; baseL += WT[4 + w]; }
+        nR += WT[w];
+        nL += WT[4 + w];
+    }
+    if (nL > SP_CAP || nR > SP_CAP || (long)nL * nR * 5 >= (long)W * W * 4) {
+        if (tid == 0) sum_sim[rowpix] = -1.0f;         // left to spamat_fwd_mfma (marker launch)
+        return;
+    }
+    {
+        int er = baseR + ir - cr, el = baseL + il - cl; // exclusive counts at p4
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            RK[p4 + k] = er;
+            if (fr & (1 << k)) XR[er++] = p4 + k;
+            RKL[p4 + k] = el;
+            if (fl & (1 << k)) XL[el++] = p4 + k;
+        }
+        if (tid == 0) { RK[1024] = nR; RKL[1024] = nL; }
+        if (tid < 16) XR[nR + tid] = 1 << 20;           // padding of the last tile: d < 0, out of range
+    }
+    __syncthreads();
+
+    // ---- 2. features of the active pixels (loads first, LDS stores after the span selection)
+    float rf[CQ], lf[CQ];
+    const int xr_own = tid < nR ? XR[tid] : -1, xl_own = tid < nL ? XL[tid] : -1;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+        rf[c] = (xr_own >= 0 && c < C) ? rrow[(size_t)c * plane + xr_own] : 0.f;
+        lf[c] = (xl_own >= 0 && c < C) ? lrow[(size_t)c * plane + xl_own] : 0.f;
+    }
+    // span: a power-of-two number of pixels holding <= ~16 active left pixels whose disparity
+    // window holds at most 16*NTC - 15 active right pixels everywhere
+    int S = 128;
+    while (S > 16 && (long)S * nL > 24L * W) S >>= 1;
+    for (;;) {
+        int bad = 0;
+        for (int g = tid; g * S < W; g += SP_THREADS) {
+            const int jlo = max(0, g * S - (D - 1)), jhi = min(W - 1, g * S + S - 1);
+            if ((int)RK[jhi + 1] - (int)RK[jlo] > 16 * NTC - 15) bad = 1;
+        }
+        if (!__syncthreads_or(bad)) break;
+        if (S == 16) {                                  // nothing written yet: hand the row over
+            if (tid == 0) sum_sim[rowpix] = -1.0f;
+            return;
+        }
+        S >>= 1;
+    }
+    // zero fill of the masked-off left pixels (functions/SpaMat.py:25-27 semantics)
+    for (int p = tid; p < W; p += SP_THREADS) {
+        if (RKL[p + 1] == RKL[p]) {
+            const size_t pix = rowpix + p;
+            if (MODE != MODE_VAR) out[pix] = 0.f;
+            if (MODE != MODE_MAT) var_out[pix] = 0.f;
+            sum_sim[pix] = 0.f;
+            max_cost[pix] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+        RF[c * SP_FP + tid] = rf[c];                    // slots >= nR hold zeros
+        LF[c * SP_FP + tid] = lf[c];
+        if (tid < 16) RF[c * SP_FP + SP_CAP + tid] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- 3. matching
+    const int j = lane & 15, q = lane >> 4;
+    const int ngroups = (W + S - 1) / S;
+    for (int g = wave; g < ngroups; g += SP_NWAVE) {
+        const int gx = g * S;
+        const int e0 = RKL[gx], e1 = RKL[min(gx + S, W)];
+        if (e1 == e0) continue;
+        const int jlo = max(0, gx - (D - 1)), jhi = min(W - 1, gx + S - 1);
+        const int r_lo = RK[jlo], r_hi = RK[jhi + 1];
+        const int t0 = r_lo >> 4;
+        const int ntile = r_hi > r_lo ? ((r_hi - 1) >> 4) - t0 + 1 : 0;      // <= NTC
+        for (int e = e0; e < e1; e += 16) {
+            const bool act = e + j < e1;
+            const int el = act ? e + j : e1 - 1;
+            const int xl = XL[el];
+            const size_t pix = rowpix + xl;
+            float bcur[KQ];
+#pragma unroll
+            for (int s = 0; s < KQ; ++s) bcur[s] = act ? LF[(4 * s + q) * SP_FP + el] : 0.f;
+            f32x4 acc[NTC];
+            const float *ap = RF + q * SP_FP + 16 * t0 + j;
+#pragma unroll
+            for (int m = 0; m < NTC; ++m) {
+                if (m < ntile) {
+                    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KQ; ++s)
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * SP_FP + 16 * m], bcur[s], a4, 0, 0, 0);
+                    acc[m] = a4;
+                }
+            }
+            float mx, Ssum, mu, var;
+            const float mu_in = (MODE == MODE_VAR && act) ? disparity[pix] : 0.f;
+            softmax_passes<NTC, MODE, true>(acc, ntile, D, 0, smem, 0, offXR + 16 * t0 + 4 * q, xl, mu_in, mx,
+                                            Ssum, mu, var);
+            if (act && q == 0) {
+                if (MODE != MODE_VAR) out[pix] = mu;
+                if (MODE != MODE_MAT) var_out[pix] = var;
+                sum_sim[pix] = Ssum;
+                max_cost[pix] = mx;
+            }
+        }
+    }
+}
+
 template <int NT, int KQ>
 int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
@@ -558,6 +737,29 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     if (lds > budget1 || make_layout(C, NT, XT).RP > 2048) return DECNET_ERR_UNSUPPORTED;
     const int segs = ceil_div(xt_row, XT);
     dim3 grid((unsigned)((size_t)B * H * segs)), block(THREADS);
+    // sparse rows first (KQ > 0: C <= 24; whole rows of <= 1024 pixels), the rest by the marker launch
+    static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
+    const int marker = allow_compact && !sparse_off && KQ > 0 && segs == 1 && W <= 1024;
+    if (marker) {
+        const size_t slds = 4 * (size_t)(SP_CAP + 16 + 2 * 514 + SP_CAP + 16 + 2 * 4 * KQ * SP_FP);
+#define LAUNCHS(M)                                                                                 \
+    do {                                                                                           \
+        if (slds > 64 * 1024) {                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_sparse<NT, M, (KQ ? KQ : 1)>, \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds); \
+            if (e != hipSuccess) return (int)e;                                                    \
+        }                                                                                          \
+        hipLaunchKernelGGL((spamat_fwd_sparse<NT, M, (KQ ? KQ : 1)>), dim3((unsigned)(B * H)),     \
+                           dim3(SP_THREADS), slds, stream, ref, tar, rmask, tmask, disparity, out, \
+                           var_out, sum_sim, max_cost, C, H, W, D);                                \
+    } while (0)
+        if (mode == MODE_MAT) LAUNCHS(MODE_MAT);
+        else if (mode == MODE_VAR) LAUNCHS(MODE_VAR);
+        else LAUNCHS(MODE_FUSED);
+#undef LAUNCHS
+        const int rc = decnet_launch_status();
+        if (rc) return rc;
+    }
 #define LAUNCH(M)                                                                                  \
     do {                                                                                           \
         if (lds > 64 * 1024) {                                                                     \
@@ -567,7 +769,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ>), grid, block, lds, stream, ref, tar, rmask, \
                            tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT, \
-                           allow_compact);                                                         \
+                           allow_compact, marker);                                                 \
     } while (0)
     if (mode == MODE_MAT) LAUNCH(MODE_MAT);
     else if (mode == MODE_VAR) LAUNCH(MODE_VAR);

@@ -156,6 +156,39 @@ def test_wide_rows_and_other_configs(dev, B, C, H, W, D, p):
     assert np.abs(dR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
 
 
+@pytest.mark.parametrize("C,W,D", [(8, 972, 216), (8, 640, 216), (24, 324, 72)])
+def test_mixed_row_densities_sparse_kernel_and_handover(dev, C, W, D):
+    """Rows of every kind in one call: very sparse (sparse-row kernel), dense and medium (handed to
+    the band kernel through the -1 marker), > 256 active pixels on one side only, a dense cluster
+    of active right pixels inside an otherwise sparse row (windows too full even for 16-pixel
+    spans -> handed over after the span search), empty rows.  SpaMat, SpaVar and the fused call."""
+    import decnet_amd
+    H = 12
+    g = torch.Generator().manual_seed(77)
+    L = torch.relu(torch.randn(1, C, H, W, generator=g))
+    R = torch.relu(torch.randn(1, C, H, W, generator=g))
+    dens = [(0.02, 0.02), (1.0, 1.0), (0.1, 0.1), (0.5, 0.5), (0.05, 0.9), (0.9, 0.05), (0.2, 0.2),
+            (0.0, 0.3), (0.3, 0.0), (0.26, 0.26), (0.03, 0.03), (0.03, 0.03)]
+    rm = torch.stack([(torch.rand(W, generator=g) < p).float() for p, _ in dens]).view(1, H, W)
+    tm = torch.stack([(torch.rand(W, generator=g) < p).float() for _, p in dens]).view(1, H, W)
+    tm[0, 10, 100:300] = 1.0                       # cluster: 200 consecutive active right pixels
+    rm[0, 11, W - 40:] = 1.0                       # cluster of active left pixels at the right edge
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    v, sv, mv = oracle.spavar_forward(L, R, rm, tm, o, D)
+    dL, dR, drm, dtm = (t.to(dev) for t in (L, R, rm, tm))
+    fo, fv, fs, fm = decnet_amd.spamatvar_forward(dL, dR, drm, dtm, D)
+    check_fwd(o, s, m, fo, fs, fm, D)
+    np.testing.assert_allclose(fv.cpu().numpy(), v, rtol=2e-4, atol=3e-3)
+    from decnet_amd import ops
+    o2, s2, m2 = (torch.full((1, H, W), -3.0, device=dev) for _ in range(3))
+    ops.spamat_forward(dL, dR, drm, dtm, o2, s2, m2, D)
+    check_fwd(o, s, m, o2, s2, m2, D)
+    v3, s3, m3 = (torch.full((1, H, W), -3.0, device=dev) for _ in range(3))
+    ops.spavar_forward(dL, dR, drm, dtm, torch.from_numpy(o).to(dev), v3, s3, m3, D)
+    np.testing.assert_allclose(v3.cpu().numpy(), v, rtol=2e-4, atol=3e-3)
+    np.testing.assert_allclose(s3.cpu().numpy(), sv, rtol=2e-5, atol=1e-9)
+
+
 def test_net_callsite_golden(dev, golden_dir):
     """Arrays recorded at the sparse_matching / sparse_var call sites of the reference graph."""
     import decnet_amd
