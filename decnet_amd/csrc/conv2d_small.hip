@@ -1,0 +1,197 @@
+// decnet_amd/csrc/conv2d_small.hip -- the full-resolution, few-channel 2-D convolutions of the trunk
+// (SURVEY.md 8f-2): Conv2dUnit / Deconv2dUnit in eval mode (modules/submodule.py:15-87) =
+// conv -> BatchNorm2d(running stats) -> ReLU, fused.
+//
+// At 540x972 with 3..17 channels these layers are bandwidth-shaped (a [8,8,540,972] tensor is
+// 134 MB; 8 -> 8 channels is 576 MACs per output pixel), and the stock path runs each as three
+// kernels (MIOpen Winograd/implicit-GEMM conv, BatchNorm, ReLU: 0.35-1.0 ms per layer).  Here a
+// thread owns one output pixel and all (<= 8) output channels: the input taps come through L1
+// (neighbouring pixels share them), the weights are wave-uniform (scalar loads), BN is a folded
+// per-channel scale/shift, and every tensor is read / written exactly once.
+//   conv2d_small<CO,K>     k = 1 or 3, stride 1, dilation d, padding d*(k/2)       (Conv2dUnit)
+//   deconv2d_k3s3<CO>      ConvTranspose2d k = 3, stride 3, padding 0: every output pixel has exactly
+//                          one tap, in[y/3][x/3] * w[ci][co][y%3][x%3]              (Deconv2dUnit)
+//   conv2d_k3s3<CO>        k = 3, stride 3, padding 1 (the down-sampling convs of FeatExtNet)
+#include "common.h"
+
+typedef int i32x4_c __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// A thread owns 4 consecutive output pixels x CO output channels.  Input taps are bounds-checked
+// 16-byte buffer loads against a descriptor of ONE input row (base = row start, size = W floats):
+// dwords past the end of the row read as zero one by one, and a load that STARTS left of the row
+// (negative = huge unsigned offset) reads as zero entirely (tools/ubench/buf_oob.hip) -- so only
+// the one thread per row whose left tap straddles x = 0 patches up to three dwords; no other
+// branch or select in the loop.  Weights [Cin][K][K][CO] are wave-uniform scalar loads.
+template <int CO, int K>
+__global__ __launch_bounds__(256) void conv2d_small(const float *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ scale,
+                                                    const float *__restrict__ shift, float *__restrict__ y,
+                                                    int Cin, int Cout, int H, int W, int dil, int relu) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, yy = blockIdx.y, b = blockIdx.z;
+    if (x0 >= W) return;
+    const size_t plane = (size_t)H * W;
+    const float *xb = x + (size_t)b * Cin * plane;
+    const int xl = x0 - (K / 2) * dil;                                   // first element of the left tap
+    const bool straddle = xl < 0 && xl > -4;
+    float acc[CO][4];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[co][e] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float *xp = xb + (size_t)ci * plane;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yi = yy + (ky - K / 2) * dil;
+            if ((unsigned)yi >= (unsigned)H) continue;                   // block-uniform
+            const __amdgpu_buffer_rsrc_t rr =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(xp + (size_t)yi * W), 0, W * 4, 0x00020000);
+            float v[K][4];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const i32x4_c t = __builtin_amdgcn_raw_buffer_load_b128(rr, (x0 + (kx - K / 2) * dil) * 4, 0, 0);
+                v[kx][0] = __int_as_float(t.x); v[kx][1] = __int_as_float(t.y);
+                v[kx][2] = __int_as_float(t.z); v[kx][3] = __int_as_float(t.w);
+            }
+            if (K > 1 && straddle) {
+#pragma unroll
+                for (int e = 1; e < 4; ++e)
+                    if (xl + e >= 0) v[0][e] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (xl + e) * 4, 0, 0));
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {                  // co >= Cout: zero weights (packed so)
+                    const float wv = w[((ci * K + ky) * K + kx) * CO + co];     // wave-uniform, co contiguous
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[co][e] = fmaf(v[kx][e], wv, acc[co][e]);
+                }
+        }
+    }
+    const bool vec = (W & 3) == 0 && ((uintptr_t)y & 15) == 0;
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+        if (co < Cout) {
+            const float sc = scale[co], sh = shift[co];
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = fmaf(acc[co][e], sc, sh);
+                if (relu) o[e] = fmaxf(o[e], 0.f);
+            }
+            float *yp = y + ((size_t)b * Cout + co) * plane + (size_t)yy * W + x0;
+            if (vec) {
+                *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x0 + e < W) yp[e] = o[e];
+            }
+        }
+}
+
+// weights packed [Cin][3][3][CO] (decnet_conv2d_pack_weight, transposed = 1); output (3H) x (3W)
+template <int CO>
+__global__ __launch_bounds__(256) void deconv2d_k3s3(const float *__restrict__ x, const float *__restrict__ w,
+                                                     const float *__restrict__ scale,
+                                                     const float *__restrict__ shift, float *__restrict__ y,
+                                                     int Cin, int Cout, int H, int W, int relu) {
+    const int Wo = 3 * W, Ho = 3 * H;
+    const int xo = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y, b = blockIdx.z;
+    if (xo >= Wo) return;
+    const int xi = xo / 3, kx = xo - 3 * xi, yi = yo / 3, ky = yo - 3 * yi;
+    const size_t plane = (size_t)H * W;
+    const float *xp = x + (size_t)b * Cin * plane + (size_t)yi * W + xi;
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float v = xp[(size_t)ci * plane];
+        const float *wp = w + ((ci * 3 + ky) * 3) * CO;                  // [ci][ky][kx][co], wave-uniform
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const float w0 = wp[co], w1 = wp[CO + co], w2 = wp[2 * CO + co];
+            acc[co] = fmaf(v, kx == 0 ? w0 : kx == 1 ? w1 : w2, acc[co]);
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+        if (co < Cout) {
+            float v = fmaf(acc[co], scale[co], shift[co]);
+            if (relu) v = fmaxf(v, 0.f);
+            y[(((size_t)b * Cout + co) * Ho + yo) * Wo + xo] = v;
+        }
+}
+
+// [Cout][Cin][k][k] (Conv2d) or [Cin][Cout][k][k] (ConvTranspose2d) -> [Cin][k][k][CO], zero padded in co
+__global__ void pack_weight2d(const float *__restrict__ w, float *__restrict__ wp, int Cin, int Cout, int kk,
+                              int CO, int transposed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * kk * CO) return;
+    const int co = i % CO, t = (i / CO) % kk, ci = i / (CO * kk);
+    float v = 0.f;
+    if (co < Cout) v = transposed ? w[((size_t)ci * Cout + co) * kk + t] : w[((size_t)co * Cin + ci) * kk + t];
+    wp[i] = v;
+}
+
+__host__ __device__ constexpr int co_pad(int Cout) { return Cout <= 1 ? 1 : Cout <= 4 ? 4 : 8; }
+
+template <int CO>
+int launch_conv(const float *x, const float *w, const float *scale, const float *shift, float *y, int B,
+                int Cin, int Cout, int H, int W, int k, int dil, int relu, hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(W, 1024), (unsigned)H, (unsigned)B);
+    if (k == 3)
+        hipLaunchKernelGGL((conv2d_small<CO, 3>), grid, dim3(256), 0, s, x, w, scale, shift, y, Cin, Cout, H, W,
+                           dil, relu);
+    else
+        hipLaunchKernelGGL((conv2d_small<CO, 1>), grid, dim3(256), 0, s, x, w, scale, shift, y, Cin, Cout, H, W,
+                           dil, relu);
+    return decnet_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t decnet_conv2d_packed_floats(int Cin, int Cout, int k, int transposed) {
+    if (Cin < 1 || Cout < 1 || Cout > 8 || (k != 1 && k != 3) || (transposed && k != 3)) return 0;
+    return (size_t)Cin * k * k * (transposed ? 8 : co_pad(Cout));
+}
+
+int decnet_conv2d_pack_weight(const float *w, float *w_packed, int Cin, int Cout, int k, int transposed,
+                              void *stream) {
+    if (!w || !w_packed) return DECNET_ERR_NULL_POINTER;
+    const int n = (int)decnet_conv2d_packed_floats(Cin, Cout, k, transposed);
+    if (n == 0) return DECNET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_weight2d, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w, w_packed, Cin,
+                       Cout, k * k, transposed ? 8 : co_pad(Cout), transposed);
+    return decnet_launch_status();
+}
+
+int decnet_conv2d_bn_act(const float *x, const float *w, const float *scale, const float *shift, float *y,
+                         int B, int Cin, int Cout, int H, int W, int k, int dilation, int relu,
+                         void *stream) {
+    if (!x || !w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
+    if ((k != 1 && k != 3) || Cout > 8 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;
+    if ((double)B * (Cin > Cout ? Cin : Cout) * H * W >= 9.0e18) return DECNET_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 1) return launch_conv<1>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
+    if (Cout <= 4) return launch_conv<4>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
+    return launch_conv<8>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
+}
+
+int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w, const float *scale, const float *shift,
+                                float *y, int B, int Cin, int Cout, int H, int W, int relu, void *stream) {
+    if (!x || !w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
+    if (Cout > 8 || 3 * H > 65535 || B > 65535 || 3.0 * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)ceil_div(3 * W, 256), (unsigned)(3 * H), (unsigned)B);
+    hipLaunchKernelGGL((deconv2d_k3s3<8>), grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, Cin,
+                       Cout, H, W, relu);
+    return decnet_launch_status();
+}
+
+}  // extern "C"

@@ -12,6 +12,8 @@ from small spec tables below with the reference's attribute names, so a referenc
 Inference only (``model.eval()``, ``torch.no_grad()``): the reference's training entry point is
 not runnable as shipped.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -34,7 +36,83 @@ class Unit(nn.Module):
         self.bn = nn.BatchNorm2d(cout, momentum=momentum) if bn else None
         self.relu = relu
 
+    # ---- fused HIP path for the full-resolution few-channel layers (csrc/conv2d_small.hip) ----
+    def _hip_kind(self, x):
+        """"conv" / "deconv" when this unit, in eval mode on the GPU, is one the small-channel kernels
+        cover (they pay off where the tensors are large: >= 64 k pixels per image); else None."""
+        if self.training or not x.is_cuda or x.dtype != torch.float32 or torch.is_grad_enabled():
+            return None
+        if os.environ.get("DECNET_CONV2D", "hip") != "hip":
+            return None
+        c = self.conv
+        up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
+        if c.out_channels > 8 or x.shape[-1] * x.shape[-2] * up < 65536:
+            return None
+        if isinstance(c, nn.ConvTranspose2d):
+            ok = (c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (0, 0) and
+                  c.output_padding == (0, 0) and c.dilation == (1, 1) and c.groups == 1)
+            return "deconv" if ok else None
+        k = c.kernel_size[0]
+        ok = (c.kernel_size in ((1, 1), (3, 3)) and c.stride == (1, 1) and c.dilation[0] == c.dilation[1] and
+              c.padding == (c.dilation[0] * (k // 2),) * 2 and c.groups == 1 and c.padding_mode == "zeros")
+        return "conv" if ok else None
+
+    def _folded(self):
+        """Per-channel scale / shift of the eval-mode BatchNorm (or 1 / bias), cached per weight version."""
+        c, bn = self.conv, self.bn
+        ts = [c.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else
+                           ([c.bias] if c.bias is not None else []))
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_fold_key", None) != key:
+            with torch.no_grad():
+                co = c.out_channels
+                if bn is not None:
+                    scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                    shift = bn.bias.float() - bn.running_mean.float() * scale
+                else:
+                    scale = torch.ones(co, device=c.weight.device)
+                    shift = c.bias.float() if c.bias is not None else torch.zeros(co, device=c.weight.device)
+                from . import _lib
+                L = _lib.lib()
+                tr = 1 if isinstance(c, nn.ConvTranspose2d) else 0
+                w = c.weight.detach().float().contiguous()
+                k = c.kernel_size[0]
+                wp = torch.empty(L.decnet_conv2d_packed_floats(c.in_channels, co, k, tr), dtype=torch.float32,
+                                 device=w.device)
+                with torch.cuda.device(w.device):
+                    _lib.check(L.decnet_conv2d_pack_weight(w.data_ptr(), wp.data_ptr(), c.in_channels, co, k, tr,
+                                                           torch.cuda.current_stream(w.device).cuda_stream),
+                               "decnet_conv2d_pack_weight")
+                self._fold = (wp, scale.contiguous(), shift.contiguous())
+            self._fold_key = key
+        return self._fold
+
+    def _forward_hip(self, x, kind):
+        from . import _lib
+        from .ops import _stream
+        x = x.contiguous()
+        w, scale, shift = self._folded()
+        B, Cin, H, W = x.shape
+        Co = self.conv.out_channels
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            if kind == "deconv":
+                y = torch.empty((B, Co, 3 * H, 3 * W), dtype=torch.float32, device=x.device)
+                rc = L.decnet_deconv2d_k3s3_bn_act(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                   y.data_ptr(), B, Cin, Co, H, W, 1 if self.relu else 0,
+                                                   _stream(x))
+            else:
+                y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+                rc = L.decnet_conv2d_bn_act(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                            y.data_ptr(), B, Cin, Co, H, W, self.conv.kernel_size[0],
+                                            self.conv.dilation[0], 1 if self.relu else 0, _stream(x))
+        _lib.check(rc, "decnet_conv2d_bn_act" if kind == "conv" else "decnet_deconv2d_k3s3_bn_act")
+        return y
+
     def forward(self, x):
+        kind = self._hip_kind(x)
+        if kind is not None:
+            return self._forward_hip(x, kind)
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)

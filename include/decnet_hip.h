@@ -163,6 +163,28 @@ int decnet_conv3d_cout1_softargmax_ws(const float *x, const float *w_oidhw, floa
 int decnet_disparity_regression(const float *cost, const float *samples, float *pred, int B,
                                 int S, int H, int W, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * 2-D trunk: the full-resolution, few-channel Conv2dUnit / Deconv2dUnit layers
+ * (modules/submodule.py:15-87) in eval mode, conv -> BatchNorm2d(running stats) -> ReLU fused:
+ *   y = act(conv(x) * scale[co] + shift[co]);  x [B,Cin,H,W], y [B,Cout,H',W'] NCHW;
+ *   scale/shift: folded BN (or 1 / bias when the unit has no BN).  Cout <= 8.
+ * Weights are repacked once by decnet_conv2d_pack_weight into decnet_conv2d_packed_floats(...)
+ * floats: torch [Cout,Cin,k,k] (transposed = 0) or ConvTranspose2d [Cin,Cout,3,3] (transposed = 1)
+ * -> [Cin][k][k][co padded].
+ * decnet_conv2d_bn_act: k = 1 or 3, stride 1, padding dilation*(k/2) (output size = input size).
+ * decnet_deconv2d_k3s3_bn_act: ConvTranspose2d k = 3, stride 3, padding 0 (output 3H x 3W;
+ *   submodule.py:162-178 Deconv2dBlock, GenerateSparseMask).
+ * ------------------------------------------------------------------------------------- */
+size_t decnet_conv2d_packed_floats(int Cin, int Cout, int k, int transposed);   /* 0: unsupported */
+int decnet_conv2d_pack_weight(const float *w, float *w_packed, int Cin, int Cout, int k,
+                              int transposed, void *stream);
+int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *scale,
+                         const float *shift, float *y, int B, int Cin, int Cout, int H, int W, int k, int dilation,
+                         int relu, void *stream);
+int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w_packed, const float *scale,
+                                const float *shift, float *y, int B, int Cin, int Cout, int H,
+                                int W, int relu, void *stream);
+
 /* Layout helpers between the reference's [B,C,D,H,W] and the internal [B,D,H,W,C]. */
 int decnet_ncdhw_to_ndhwc(const float *src, float *dst, int B, int C, int D, int H, int W,
                           void *stream);
