@@ -109,10 +109,34 @@ class Unit(nn.Module):
         _lib.check(rc, "decnet_conv2d_bn_act" if kind == "conv" else "decnet_deconv2d_k3s3_bn_act")
         return y
 
+    def _folded_torch(self):
+        """Eval-mode BatchNorm folded into the convolution itself (w * scale per output channel, bias =
+        shift) for the layers that stay on MIOpen: one kernel instead of conv + batch-norm."""
+        c, bn = self.conv, self.bn
+        key = tuple((t.data_ptr(), t._version) for t in (c.weight, bn.weight, bn.bias, bn.running_mean,
+                                                         bn.running_var))
+        if getattr(self, "_tfold_key", None) != key:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+                shape = (1, -1, 1, 1) if isinstance(c, nn.ConvTranspose2d) else (-1, 1, 1, 1)
+                self._tfold = ((c.weight * scale.view(shape)).contiguous(), shift.contiguous())
+            self._tfold_key = key
+        return self._tfold
+
     def forward(self, x):
         kind = self._hip_kind(x)
         if kind is not None:
             return self._forward_hip(x, kind)
+        if (self.bn is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda and
+                os.environ.get("DECNET_FOLD_BN", "1") == "1"):
+            w, b = self._folded_torch()
+            c = self.conv
+            if isinstance(c, nn.ConvTranspose2d):
+                x = F.conv_transpose2d(x, w, b, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
+            else:
+                x = F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
+            return torch.relu_(x) if self.relu else x
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)
