@@ -239,8 +239,10 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
     int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker) {
     // marker: this launch follows spamat_fwd_sparse, which left -1 in sum_sim[row start] of exactly
-    // the rows it did not take (a real sum_similarities is never negative)
-    if (marker && sum_sim[(size_t)blockIdx.x * W] != -1.0f) return;
+    // the rows it did not take, at the first pixel of every segment (a real sum_similarities is never
+    // negative)
+    if (marker && sum_sim[(size_t)(blockIdx.x / segs_per_row) * W + (size_t)(blockIdx.x % segs_per_row) * (XT * 16)] != -1.0f)
+        return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Layout lo = make_layout(C, NT, XT);
     float *Rs = smem + lo.offR;
@@ -555,19 +557,22 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
 // marker = 1: this kernel writes -1 to sum_sim[row start] of exactly those rows.
 constexpr int SP_THREADS = 256, SP_NWAVE = SP_THREADS / 64, SP_CAP = 256, SP_FP = SP_CAP + 16;
 
-template <int NT, int MODE, int KQ>
-__global__ __launch_bounds__(SP_THREADS, 6) void spamat_fwd_sparse(
+// PPT = pixels per thread of the mask scan: 4 (W <= 1024) or 8 (W <= 2048).  seg_w = pixels per
+// segment of the marker launch (it splits rows wider than 1024 pixels): one marker per segment.
+template <int NT, int MODE, int KQ, int PPT>
+__global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_sparse(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D) {
+    int H, int W, int D, int seg_w) {
     // at most 8 cost tiles per span (32 accumulator registers: six workgroups per CU); a row whose
     // disparity windows hold more than 8*16-15 active right pixels even for 16-pixel spans goes to
     // spamat_fwd_mfma like the dense ones
     constexpr int CQ = 4 * KQ, NTC = NT + 1 < 8 ? NT + 1 : 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // words: XR [CAP+16] | RK [1028 x u16] | RKL [1028 x u16] | XL [CAP] | WT [16] | RF [CQ][FP] | LF [CQ][FP]
-    constexpr int offXR = 0, offRK = SP_CAP + 16, offRKL = offRK + 514, offXL = offRKL + 514,
+    // words: XR [CAP+16] | RK [(NPX+4) x u16] | RKL [(NPX+4) x u16] | XL [CAP] | WT [16] | RF [CQ][FP] | LF [CQ][FP]
+    constexpr int NPX = SP_THREADS * PPT, RKW = NPX / 2 + 2;               // RK / RKL: NPX + 4 u16
+    constexpr int offXR = 0, offRK = SP_CAP + 16, offRKL = offRK + RKW, offXL = offRKL + RKW,
                   offWT = offXL + SP_CAP, offRF = offWT + 16, offLF = offRF + CQ * SP_FP;
     int *XR = reinterpret_cast<int *>(smem) + offXR;
     unsigned short *RK = reinterpret_cast<unsigned short *>(smem + offRK);
@@ -584,14 +589,17 @@ __global__ __launch_bounds__(SP_THREADS, 6) void spamat_fwd_sparse(
     const float *trow = tmask + rowpix, *mrow = rmask + rowpix;
 
     // ---- 1. masks -> bits, counts
-    const int p4 = tid * 4;
+    const int p4 = tid * PPT;                        // this thread's PPT consecutive pixels
     int fr = 0, fl = 0;
     {
         const bool alm = ((W & 3) == 0) && ((((uintptr_t)trow) | ((uintptr_t)mrow)) & 15) == 0;
-        if (p4 < W) {
-            const float4 tv = load4(trow, p4, W, alm), mv = load4(mrow, p4, W, alm);
-            fr = (tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3);
-            fl = (mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3);
+#pragma unroll
+        for (int u = 0; u < PPT; u += 4) {
+            if (p4 + u < W) {
+                const float4 tv = load4(trow, p4 + u, W, alm), mv = load4(mrow, p4 + u, W, alm);
+                fr |= ((tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3)) << u;
+                fl |= ((mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3)) << u;
+            }
         }
     }
     const int cr = __popc(fr), cl = __popc(fl);
@@ -605,20 +613,23 @@ __global__ __launch_bounds__(SP_THREADS, 6) void spamat_fwd_sparse(
         nR += WT[w];
         nL += WT[4 + w];
     }
+    auto hand_over = [&]() {                           // left to spamat_fwd_mfma (marker launch)
+        for (int x = tid * seg_w; x < W; x += SP_THREADS * seg_w) sum_sim[rowpix + x] = -1.0f;
+    };
     if (nL > SP_CAP || nR > SP_CAP || (long)nL * nR * 5 >= (long)W * W * 4) {
-        if (tid == 0) sum_sim[rowpix] = -1.0f;         // left to spamat_fwd_mfma (marker launch)
+        hand_over();
         return;
     }
     {
         int er = baseR + ir - cr, el = baseL + il - cl; // exclusive counts at p4
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PPT; ++k) {
             RK[p4 + k] = er;
             if (fr & (1 << k)) XR[er++] = p4 + k;
             RKL[p4 + k] = el;
             if (fl & (1 << k)) XL[el++] = p4 + k;
         }
-        if (tid == 0) { RK[1024] = nR; RKL[1024] = nL; }
+        if (tid == 0) { RK[NPX] = nR; RKL[NPX] = nL; }
         if (tid < 16) XR[nR + tid] = 1 << 20;           // padding of the last tile: d < 0, out of range
     }
     __syncthreads();
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(SP_THREADS, 6) void spamat_fwd_sparse(
         }
         if (!__syncthreads_or(bad)) break;
         if (S == 16) {                                  // nothing written yet: hand the row over
-            if (tid == 0) sum_sim[rowpix] = -1.0f;
+            hand_over();
             return;
         }
         S >>= 1;
@@ -737,25 +748,33 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     if (lds > budget1 || make_layout(C, NT, XT).RP > 2048) return DECNET_ERR_UNSUPPORTED;
     const int segs = ceil_div(xt_row, XT);
     dim3 grid((unsigned)((size_t)B * H * segs)), block(THREADS);
-    // sparse rows first (KQ > 0: C <= 24; whole rows of <= 1024 pixels), the rest by the marker launch
+    // sparse rows first (KQ > 0: C <= 24; rows of <= 2048 pixels), the rest by the marker launch
     static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
-    const int marker = allow_compact && !sparse_off && KQ > 0 && segs == 1 && W <= 1024;
+    const int marker = allow_compact && !sparse_off && KQ > 0 && W <= 2048;
     if (marker) {
-        const size_t slds = 4 * (size_t)(SP_CAP + 16 + 2 * 514 + SP_CAP + 16 + 2 * 4 * KQ * SP_FP);
-#define LAUNCHS(M)                                                                                 \
+        const int ppt = W <= 1024 ? 4 : 8;
+        const size_t slds = 4 * (size_t)(SP_CAP + 16 + 2 * (SP_THREADS * ppt / 2 + 2) + SP_CAP + 16 +
+                                         2 * 4 * KQ * SP_FP);
+#define LAUNCHS(M, P)                                                                              \
     do {                                                                                           \
         if (slds > 64 * 1024) {                                                                    \
-            hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_sparse<NT, M, (KQ ? KQ : 1)>, \
+            hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_sparse<NT, M, (KQ ? KQ : 1), P>, \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds); \
             if (e != hipSuccess) return (int)e;                                                    \
         }                                                                                          \
-        hipLaunchKernelGGL((spamat_fwd_sparse<NT, M, (KQ ? KQ : 1)>), dim3((unsigned)(B * H)),     \
+        hipLaunchKernelGGL((spamat_fwd_sparse<NT, M, (KQ ? KQ : 1), P>), dim3((unsigned)(B * H)),  \
                            dim3(SP_THREADS), slds, stream, ref, tar, rmask, tmask, disparity, out, \
-                           var_out, sum_sim, max_cost, C, H, W, D);                                \
+                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16);                       \
     } while (0)
-        if (mode == MODE_MAT) LAUNCHS(MODE_MAT);
-        else if (mode == MODE_VAR) LAUNCHS(MODE_VAR);
-        else LAUNCHS(MODE_FUSED);
+#define LAUNCHSP(M)                                                                                \
+    do {                                                                                           \
+        if (ppt == 4) LAUNCHS(M, 4);                                                               \
+        else LAUNCHS(M, 8);                                                                        \
+    } while (0)
+        if (mode == MODE_MAT) LAUNCHSP(MODE_MAT);
+        else if (mode == MODE_VAR) LAUNCHSP(MODE_VAR);
+        else LAUNCHSP(MODE_FUSED);
+#undef LAUNCHSP
 #undef LAUNCHS
         const int rc = decnet_launch_status();
         if (rc) return rc;

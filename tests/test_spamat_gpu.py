@@ -156,7 +156,9 @@ def test_wide_rows_and_other_configs(dev, B, C, H, W, D, p):
     assert np.abs(dR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
 
 
-@pytest.mark.parametrize("C,W,D", [(8, 972, 216), (8, 640, 216), (24, 324, 72)])
+@pytest.mark.parametrize("C,W,D", [(8, 972, 216), (8, 640, 216), (24, 324, 72),
+                                   (8, 1242, 216),      # KITTI stage 3: 8 pixels per thread, 2 marker segments
+                                   (8, 1512, 270)])     # Middlebury half-res stage 3
 def test_mixed_row_densities_sparse_kernel_and_handover(dev, C, W, D):
     """Rows of every kind in one call: very sparse (sparse-row kernel), dense and medium (handed to
     the band kernel through the -1 marker), > 256 active pixels on one side only, a dense cluster
