@@ -19,6 +19,8 @@
 //                 per-left-pixel scalars (max, out, g/S, mu, mask) are rows of the tile: LDS planes.
 // LDS: Os[Cq][OP] (OP == 4 mod 64: the contraction reads 4 consecutive pixels of one channel per
 //      lane with ds_read_b128, 16 channels x 4 quads conflict-free) | planes[NPL][OW].
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -28,6 +30,7 @@ namespace {
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int THREADS = 512, NWAVE = THREADS / 64;
+constexpr int BWD_MARK = 0x7fc0dec0;     // a NaN payload no gradient takes: "row left to the band kernel"
 
 __device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, int W, bool aligned) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -65,7 +68,14 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
     const float *__restrict__ out, const float *__restrict__ sum_sim,
     const float *__restrict__ max_cost, const float *__restrict__ grad_out,
     float *__restrict__ grad_own, float *__restrict__ grad_disp, int C, int H, int W, int D,
-    int segs_per_row, int XT) {
+    int segs_per_row, int XT, int marker) {
+    // marker: this launch follows spamat_bwd_sparse, which left BWD_MARK in channel 0 of grad_own at
+    // the first pixel of every segment of exactly the rows it did not take
+    if (marker) {
+        const int sg = blockIdx.x % segs_per_row, rw = blockIdx.x / segs_per_row;
+        const size_t at = ((size_t)(rw / H) * C * H + (rw % H)) * W + (size_t)sg * (XT * 16);
+        if (__float_as_int(grad_own[at]) != BWD_MARK) return;
+    }
     constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
     constexpr int NCB = (4 * KQ + 15) / 16;          // 16-channel blocks of the contraction
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -261,11 +271,9 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
     }
 }
 
-template <int NT, bool VAR, int KQ, int SIDE>
-int launch_side(const float *ref, const float *tar, const float *rmask, const float *tmask,
-                const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
-                const float *grad_out, float *grad_own, float *grad_disp, int B, int C, int H, int W,
-                int D, hipStream_t stream) {
+// tiles per segment of the band kernel for one side (0 = does not fit)
+template <int NT, bool VAR, int SIDE>
+int side_xt(int C, int W) {
     constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
     const int xt_row = ceil_div(W, 16);
     auto bytes = [&](int xt) { return (size_t)4 * make_blayout(C, NT, xt, NPL).total; };
@@ -280,9 +288,17 @@ int launch_side(const float *ref, const float *tar, const float *rmask, const fl
             while (XT > 1 && bytes(XT) > budget1) --XT;
     }
     XT = (XT + 3) & ~3;                                  // segment starts stay 64-float aligned
-    const size_t lds = bytes(XT);
-    if (lds > budget1) return DECNET_ERR_UNSUPPORTED;
-    const int segs = ceil_div(xt_row, XT);
+    return bytes(XT) > budget1 ? 0 : XT;
+}
+
+template <int NT, bool VAR, int KQ, int SIDE>
+int launch_side(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
+                const float *grad_out, float *grad_own, float *grad_disp, int B, int C, int H, int W,
+                int D, int XT, int marker, hipStream_t stream) {
+    constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
+    const size_t lds = (size_t)4 * make_blayout(C, NT, XT, NPL).total;
+    const int segs = ceil_div(ceil_div(W, 16), XT);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)spamat_bwd_mfma<NT, VAR, KQ, SIDE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -290,8 +306,272 @@ int launch_side(const float *ref, const float *tar, const float *rmask, const fl
     }
     hipLaunchKernelGGL((spamat_bwd_mfma<NT, VAR, KQ, SIDE>), dim3((unsigned)((size_t)B * H * segs)),
                        dim3(THREADS), lds, stream, ref, tar, rmask, tmask, disparity, out, sum_sim,
-                       max_cost, grad_out, grad_own, grad_disp, C, H, W, D, segs, XT);
+                       max_cost, grad_out, grad_own, grad_disp, C, H, W, D, segs, XT, marker);
     return decnet_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse rows (<= 256 active pixels on each side): as spamat_mfma.hip:spamat_fwd_sparse, nothing but
+// the masks, the features of the ACTIVE pixels and the per-left-pixel scalars is read, and both
+// gradients of a row come out of one workgroup:
+//   1. mask rows -> bits, exclusive counts (RK / RKL), index lists XR / XL
+//   2. gather RF / LF [C][slot] and NM = -max*log2e, OUT, GS = g/S (, MU) per active left pixel;
+//      zero-fill the gradients of the inactive pixels meanwhile
+//   3. gL: chunks of 16 consecutive ACTIVE left pixels x 16-wide tiles of the compacted right list
+//      inside their disparity window: cost tile -> weight -> contraction, exactly the arithmetic of
+//      spamat_bwd_mfma; then gR with the roles swapped (and grad_disparity for SpaVar).
+// Nothing is kept per tile, so there is no limit on the number of tiles of a window.  Rows with more
+// active pixels are left to the band kernels: BWD_MARK is written into channel 0 of both gradients
+// at the first pixel of each of their segments (seg_w0 / seg_w1 pixels wide).
+constexpr int SB_THREADS = 256, SB_NWAVE = SB_THREADS / 64, SB_CAP = 256, SB_LP = SB_CAP + 16, SB_FP = 324;
+
+__device__ __forceinline__ int wave_incl_scan_b(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+template <bool VAR, int KQ, int PPT>
+__global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity,
+    const float *__restrict__ out, const float *__restrict__ sum_sim,
+    const float *__restrict__ max_cost, const float *__restrict__ grad_out,
+    float *__restrict__ grad_ref, float *__restrict__ grad_tar, float *__restrict__ grad_disp, int C,
+    int H, int W, int D, int seg_w0, int seg_w1) {
+    constexpr int CQ = 4 * KQ, NCB = (CQ + 15) / 16, NPX = SB_THREADS * PPT, RKW = NPX / 2 + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // words: XR [LP] | XL [LP] | RK, RKL [(NPX+4) x u16] | WT [16] | NM, OUT, GS, MU [LP] | RF, LF [CQ][FP]
+    constexpr int offXR = 0, offXL = SB_LP, offRK = 2 * SB_LP, offRKL = offRK + RKW, offWT = offRKL + RKW,
+                  offNM = offWT + 16, offOUT = offNM + SB_LP, offGS = offOUT + SB_LP, offMU = offGS + SB_LP,
+                  offRF = offMU + SB_LP, offLF = offRF + CQ * SB_FP;
+    int *XR = reinterpret_cast<int *>(smem) + offXR;
+    int *XL = reinterpret_cast<int *>(smem) + offXL;
+    unsigned short *RK = reinterpret_cast<unsigned short *>(smem + offRK);
+    unsigned short *RKL = reinterpret_cast<unsigned short *>(smem + offRKL);
+    int *WT = reinterpret_cast<int *>(smem) + offWT;
+    float *NM = smem + offNM, *OUT = smem + offOUT, *GS = smem + offGS, *MU = smem + offMU;
+    float *RF = smem + offRF, *LF = smem + offLF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, b = row / H, y = row - b * H;
+    const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
+    const float *lrow = ref + ((size_t)b * C * H + y) * W;
+    const float *rrow = tar + ((size_t)b * C * H + y) * W;
+    float *glrow = grad_ref + ((size_t)b * C * H + y) * W;
+    float *grrow = grad_tar + ((size_t)b * C * H + y) * W;
+    const float *trow = tmask + rowpix, *mrow = rmask + rowpix;
+
+    // ---- 1. masks -> bits, counts
+    const int p0 = tid * PPT;
+    int fr = 0, fl = 0;
+    {
+        const bool alm = ((W & 3) == 0) && ((((uintptr_t)trow) | ((uintptr_t)mrow)) & 15) == 0;
+#pragma unroll
+        for (int u = 0; u < PPT; u += 4) {
+            if (p0 + u < W) {
+                const float4 tv = load4(trow, p0 + u, W, alm), mv = load4(mrow, p0 + u, W, alm);
+                fr |= ((tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3)) << u;
+                fl |= ((mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3)) << u;
+            }
+        }
+    }
+    const int cr = __popc(fr), cl = __popc(fl);
+    const int ir = wave_incl_scan_b(cr, lane), il = wave_incl_scan_b(cl, lane);
+    if (lane == 63) { WT[wave] = ir; WT[4 + wave] = il; }
+    __syncthreads();
+    int nR = 0, nL = 0, baseR = 0, baseL = 0;
+#pragma unroll
+    for (int w = 0; w < SB_NWAVE; ++w) {
+        if (w < wave) { baseR += WT[w]; baseL += WT[4 + w]; }
+        nR += WT[w];
+        nL += WT[4 + w];
+    }
+    if (nL > SB_CAP || nR > SB_CAP) {                  // left to the band kernels (marker launches)
+        for (int x = tid * seg_w0; x < W; x += SB_THREADS * seg_w0) glrow[x] = __int_as_float(BWD_MARK);
+        for (int x = tid * seg_w1; x < W; x += SB_THREADS * seg_w1) grrow[x] = __int_as_float(BWD_MARK);
+        return;
+    }
+    {
+        int er = baseR + ir - cr, el = baseL + il - cl; // exclusive counts at p0
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            RK[p0 + k] = er;
+            if (fr & (1 << k)) XR[er++] = p0 + k;
+            RKL[p0 + k] = el;
+            if (fl & (1 << k)) XL[el++] = p0 + k;
+        }
+        if (tid == 0) { RK[NPX] = nR; RKL[NPX] = nL; }
+        if (tid < 16) {                                 // padding of the last tile: d out of range
+            XR[nR + tid] = 1 << 20;
+            XL[nL + tid] = -(1 << 20);
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. gathers (all loads of a thread in flight), zero fill of the inactive pixels
+    {
+        const int xr_own = tid < nR ? XR[tid] : -1, xl_own = tid < nL ? XL[tid] : -1;
+        float rf[CQ], lf[CQ];
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            rf[c] = (xr_own >= 0 && c < C) ? rrow[(size_t)c * plane + xr_own] : 0.f;
+            lf[c] = (xl_own >= 0 && c < C) ? lrow[(size_t)c * plane + xl_own] : 0.f;
+        }
+        float nm = 0.f, oo = 0.f, gs = 0.f, mu = 0.f;
+        if (xl_own >= 0) {
+            nm = -max_cost[rowpix + xl_own] * LOG2E;
+            oo = out[rowpix + xl_own];
+            gs = grad_out[rowpix + xl_own] / sum_sim[rowpix + xl_own];
+            if (VAR) mu = disparity[rowpix + xl_own];
+        }
+        // 16-byte stores for the quads without an active pixel (most of them), scalars for the rest
+        const bool v4 = (W & 3) == 0 && (((uintptr_t)glrow | (uintptr_t)grrow | (uintptr_t)(plane * 4)) & 15) == 0;
+        auto zero_fill = [&](float *rowp, int bits, size_t cstride, int nc) {
+#pragma unroll
+            for (int u = 0; u < PPT; u += 4) {
+                if (p0 + u >= W) continue;
+                const int qb = (bits >> u) & 15;
+                if (qb == 15) continue;
+                for (int c = 0; c < nc; ++c) {
+                    float *o = rowp + (size_t)c * cstride + p0 + u;
+                    if (qb == 0 && v4) {
+                        *reinterpret_cast<float4 *>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (p0 + u + k < W && !((qb >> k) & 1)) o[k] = 0.f;
+                    }
+                }
+            }
+        };
+        zero_fill(glrow, fl, plane, C);
+        zero_fill(grrow, fr, plane, C);
+        if (VAR) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                if (p0 + k < W && !((fl >> k) & 1)) grad_disp[rowpix + p0 + k] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            RF[c * SB_FP + tid] = rf[c];                // slots >= nR / nL hold zeros
+            LF[c * SB_FP + tid] = lf[c];
+            if (tid < 16) { RF[c * SB_FP + SB_CAP + tid] = 0.f; LF[c * SB_FP + SB_CAP + tid] = 0.f; }
+        }
+        NM[tid] = nm; OUT[tid] = oo; GS[tid] = gs; MU[tid] = mu;
+        if (tid < 16) { NM[SB_CAP + tid] = 0.f; OUT[SB_CAP + tid] = 0.f; GS[SB_CAP + tid] = 0.f; MU[SB_CAP + tid] = 0.f; }
+    }
+    __syncthreads();
+
+    // ---- 3. the two gradients
+    const int j = lane & 15, q = lane >> 4;
+    const int cj = j < CQ ? j : CQ - 1;               // channel this lane supplies to the contraction
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const int n_own = side == 0 ? nL : nR;
+        const int *XO = side == 0 ? XL : XR;           // own positions
+        const int *XT = side == 0 ? XR : XL;           // other positions
+        const float *FO = side == 0 ? LF : RF, *FT = side == 0 ? RF : LF;
+        float *grow = side == 0 ? glrow : grrow;
+        for (int e = 16 * wave; e < n_own; e += 16 * SB_NWAVE) {
+            const bool act = e + j < n_own;
+            const int xo = XO[act ? e + j : n_own - 1];
+            const int x_lo = XO[e], x_hi = XO[min(e + 15, n_own - 1)];
+            // other pixels that can pair with the chunk
+            int i_lo, i_hi;
+            if (side == 0) { i_lo = RK[max(0, x_lo - (D - 1))]; i_hi = RK[x_hi + 1]; }
+            else { i_lo = RKL[x_lo]; i_hi = RKL[min(W, x_hi + D)]; }
+            float bcur[KQ];
+#pragma unroll
+            for (int s = 0; s < KQ; ++s) bcur[s] = act ? FO[(4 * s + q) * SB_FP + e + j] : 0.f;
+            float nm_own = 0.f, out_own = 0.f, mu_own = 0.f;
+            if (side == 0) { nm_own = NM[e + j]; out_own = OUT[e + j]; mu_own = MU[e + j]; }
+            f32x4 gacc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) gacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float gdis = 0.f;
+            if (i_hi > i_lo) {
+#pragma unroll 1
+                for (int t = i_lo >> 4; t <= (i_hi - 1) >> 4; ++t) {
+                    // cost tile: rows = other slots 16t + 4q + r, columns (lanes) = own slots e + j
+                    const float *ap = FT + q * SB_FP + 16 * t + j;
+                    f32x4 cst = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                    for (int s = 1; s < KQ; ++s)
+                        cst = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * SB_FP], bcur[s], cst, 0, 0, 0);
+                    const int4 xt4 = *reinterpret_cast<const int4 *>(XT + 16 * t + 4 * q);
+                    const int xtv[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
+                    float4 nmr, outr, gsr, mur;
+                    if (side == 1) {
+                        nmr = *reinterpret_cast<const float4 *>(NM + 16 * t + 4 * q);
+                        outr = *reinterpret_cast<const float4 *>(OUT + 16 * t + 4 * q);
+                        gsr = *reinterpret_cast<const float4 *>(GS + 16 * t + 4 * q);
+                        if (VAR) mur = *reinterpret_cast<const float4 *>(MU + 16 * t + 4 * q);
+                    }
+                    f32x4 wt;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = side == 0 ? xo - xtv[r] : xtv[r] - xo;
+                        const float nm = side == 0 ? nm_own : (r == 0 ? nmr.x : r == 1 ? nmr.y : r == 2 ? nmr.z : nmr.w);
+                        const float cc = ((unsigned)d < (unsigned)D && act) ? cst[r] : NEG_BIG;
+                        const float ex = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm));
+                        const float df = (float)d;
+                        float w;
+                        if (side == 0) {
+                            if (VAR) {
+                                const float dd = df - mu_own;
+                                w = ex * fmaf(dd, dd, -out_own);       // SV_kernel.cu:191
+                                gdis = fmaf(ex, dd, gdis);             // SV_kernel.cu:321
+                            } else {
+                                w = ex * (df - out_own);               // SM_kernel.cu:191
+                            }
+                        } else {
+                            const float o = r == 0 ? outr.x : r == 1 ? outr.y : r == 2 ? outr.z : outr.w;
+                            const float g = r == 0 ? gsr.x : r == 1 ? gsr.y : r == 2 ? gsr.z : gsr.w;
+                            if (VAR) {
+                                const float mu = r == 0 ? mur.x : r == 1 ? mur.y : r == 2 ? mur.z : mur.w;
+                                const float dd = df - mu;
+                                w = g * ex * fmaf(dd, dd, -o);         // SV_kernel.cu:262
+                            } else {
+                                w = g * ex * (df - o);                 // SM_kernel.cu:346
+                            }
+                        }
+                        wt[r] = w;
+                    }
+                    // contraction over the 16 other slots of the tile (K step r <-> slot 4q + r)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        const int c = 16 * cb + cj < CQ ? 16 * cb + cj : CQ - 1;
+                        const float4 ov = *reinterpret_cast<const float4 *>(FT + c * SB_FP + 16 * t + 4 * q);
+                        gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0], ov.x, gacc[cb], 0, 0, 0);
+                        gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1], ov.y, gacc[cb], 0, 0, 0);
+                        gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[2], ov.z, gacc[cb], 0, 0, 0);
+                        gacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[3], ov.w, gacc[cb], 0, 0, 0);
+                    }
+                }
+            }
+            // gacc[cb][r]: channel 16*cb + (lane & 15), own slot e + 4q + r
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int c = 16 * cb + j;
+                if (c < C) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oi = e + 4 * q + r;
+                        if (oi < n_own) grow[(size_t)c * plane + XO[oi]] = gacc[cb][r] * (side == 0 ? GS[oi] : 1.f);
+                    }
+                }
+            }
+            if (VAR && side == 0) {
+                gdis += __shfl_xor(gdis, 16);
+                gdis += __shfl_xor(gdis, 32);
+                if (act && q == 0) grad_disp[rowpix + xo] = -2.f * GS[e + j] * gdis;
+            }
+        }
+    }
 }
 
 template <int NT, bool VAR, int KQ>
@@ -299,11 +579,42 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
                 const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
                 const float *grad_out, float *grad_ref, float *grad_tar, float *grad_disp, int B, int C,
                 int H, int W, int D, hipStream_t stream) {
+    const int xt0 = side_xt<NT, VAR, 0>(C, W), xt1 = side_xt<NT, VAR, 1>(C, W);
+    if (!xt0 || !xt1) return DECNET_ERR_UNSUPPORTED;
+    // sparse rows first (C <= 24, rows of <= 2048 pixels), the rest by the marker launches
+    static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
+    int marker = 0;
+    if constexpr (KQ <= 6) {
+        if (!sparse_off && W <= 2048) {
+            marker = 1;
+            const int ppt = W <= 1024 ? 4 : 8;
+            const size_t slds = 4 * (size_t)(2 * SB_LP + 2 * (SB_THREADS * ppt / 2 + 2) + 16 + 4 * SB_LP +
+                                             2 * 4 * KQ * SB_FP);
+            if (slds > 64 * 1024) {
+                hipError_t e = ppt == 4
+                    ? hipFuncSetAttribute((const void *)spamat_bwd_sparse<VAR, KQ, 4>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds)
+                    : hipFuncSetAttribute((const void *)spamat_bwd_sparse<VAR, KQ, 8>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+                if (e != hipSuccess) return (int)e;
+            }
+            if (ppt == 4)
+                hipLaunchKernelGGL((spamat_bwd_sparse<VAR, KQ, 4>), dim3((unsigned)(B * H)), dim3(SB_THREADS), slds,
+                                   stream, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out,
+                                   grad_ref, grad_tar, grad_disp, C, H, W, D, xt0 * 16, xt1 * 16);
+            else
+                hipLaunchKernelGGL((spamat_bwd_sparse<VAR, KQ, 8>), dim3((unsigned)(B * H)), dim3(SB_THREADS), slds,
+                                   stream, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out,
+                                   grad_ref, grad_tar, grad_disp, C, H, W, D, xt0 * 16, xt1 * 16);
+            const int rc = decnet_launch_status();
+            if (rc) return rc;
+        }
+    }
     int rc = launch_side<NT, VAR, KQ, 0>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
-                                         grad_out, grad_ref, grad_disp, B, C, H, W, D, stream);
+                                         grad_out, grad_ref, grad_disp, B, C, H, W, D, xt0, marker, stream);
     if (rc) return rc;
     return launch_side<NT, VAR, KQ, 1>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
-                                       grad_out, grad_tar, nullptr, B, C, H, W, D, stream);
+                                       grad_out, grad_tar, nullptr, B, C, H, W, D, xt1, marker, stream);
 }
 
 template <int NT, bool VAR>

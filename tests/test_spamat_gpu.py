@@ -189,6 +189,23 @@ def test_mixed_row_densities_sparse_kernel_and_handover(dev, C, W, D):
     ops.spavar_forward(dL, dR, drm, dtm, torch.from_numpy(o).to(dev), v3, s3, m3, D)
     np.testing.assert_allclose(v3.cpu().numpy(), v, rtol=2e-4, atol=3e-3)
     np.testing.assert_allclose(s3.cpu().numpy(), sv, rtol=2e-5, atol=1e-9)
+    # backward through the same mix of rows: sparse-row backward kernel + marker hand-over
+    g = torch.randn(1, H, W, generator=torch.Generator().manual_seed(9))
+    gl, gr = oracle.spamat_backward(L, R, rm, tm, o, s, m, g, D)
+    aL, aR = dL.clone().requires_grad_(), dR.clone().requires_grad_()
+    decnet_amd.SpaMatFunction.apply(aL, aR, drm, dtm, D).backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+    assert np.abs(aL.grad.cpu().numpy() - gl).max() < 5e-5 * sc
+    assert np.abs(aR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
+    mu = torch.from_numpy(o) + 0.25
+    v2, s2, m2 = oracle.spavar_forward(L, R, rm, tm, mu, D)
+    gl, gr, gd = oracle.spavar_backward(L, R, rm, tm, mu, v2, s2, m2, g, D)
+    aL, aR, amu = dL.clone().requires_grad_(), dR.clone().requires_grad_(), mu.to(dev).requires_grad_()
+    decnet_amd.SpaVarFunction.apply(aL, aR, drm, dtm, amu, D).backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()), float(np.abs(gd).max()))
+    assert np.abs(aL.grad.cpu().numpy() - gl).max() < 5e-5 * sc
+    assert np.abs(aR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
+    assert np.abs(amu.grad.cpu().numpy() - gd).max() < 5e-5 * sc
 
 
 def test_net_callsite_golden(dev, golden_dir):

@@ -47,7 +47,7 @@ def main():
            "launches": {k: v[1] for k, v in fetch.items()}}
     json.dump(raw, open(raw_out, "w"), indent=1)
     res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                   "--warmup 1 --no-cpu-baseline; per-launch means (tools/pmc_summary.py). FETCH_SIZE is doubled "
+                   "--warmup 1 --no-cpu-baseline --no-e2e; per-launch means (tools/pmc_summary.py). FETCH_SIZE is doubled "
                    "as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is. FETCH/WRITE are "
                    "L2<->fabric requests: Infinity-Cache hits are included, so for kernels whose working set "
                    "stays in the 256 MiB Infinity Cache this is an upper bound on HBM bytes."}
