@@ -132,10 +132,8 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
                 acc[m][2] = (unsigned)(xlj - p.z) < (unsigned)D ? acc[m][2] : NEG_BIG;
                 acc[m][3] = (unsigned)(xlj - p.w) < (unsigned)D ? acc[m][3] : NEG_BIG;
             } else {
-                // right mask (SM_kernel.cu:48) as an additive 0 / -1e30 bias, read here (not
-                // beside the MFMAs) so that only one tile's worth is live at a time
-                const float4 bz = *reinterpret_cast<const float4 *>(bp1 - 16 * m);
-                acc[m][0] += bz.x; acc[m][1] += bz.y; acc[m][2] += bz.z; acc[m][3] += bz.w;
+                // (the right mask, SM_kernel.cu:48, is already in: the cost MFMAs start from the
+                // 0 / -1e30 bias tile instead of zeros)
                 if (m == 0 || 16 * m + 15 >= D) {
                     asm volatile("" ::: "memory");  // keep a real scalar branch (no if-conversion)
 #pragma unroll
@@ -377,11 +375,13 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
 #if DECNET_ABLATE == 1 || DECNET_ABLATE == 3
                     a4 = f32x4{ap[-16 * m], ap[(4 * RP) - 16 * m], bcur[0], bcur[KB - 1]};
 #else
+                    // accumulate on top of the right-mask bias (0 / -1e30 per right pixel = tile row):
+                    // 0 + x is exact and -1e30 + x == -1e30, so this equals adding the bias afterwards
+                    const float4 bz = *reinterpret_cast<const float4 *>(BX + (HALO + xt * 16) + 4 * q - 16 * m);
+                    a4 = f32x4{bz.x, bz.y, bz.z, bz.w};
                     if (KQ) {
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[-16 * m], bcur[0],
-                                                                 f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-                        for (int s = 1; s < KQ; ++s)
+                        for (int s = 0; s < KQ; ++s)
                             a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP - 16 * m], bcur[s], a4, 0, 0, 0);
                     } else {
                         const float *bp = lrow + (size_t)q * plane + x;   // generic C: L from L2/HBM
