@@ -92,28 +92,85 @@ __global__ __launch_bounds__(256) void conv2d_small(const float *__restrict__ x,
         }
 }
 
-// weights packed [Cin][3][3][CO] (decnet_conv2d_pack_weight, transposed = 1); output (3H) x (3W)
+// weights packed [Cin][3][3][CO] (decnet_conv2d_pack_weight, transposed = 1); output (3H) x (3W).
+// A thread owns one INPUT pixel: its Cin values are read once and produce the 3 x 3 output pixels
+// x CO channels that depend on it (and on nothing else); a wave's three stores per (co, row) fill
+// 768 contiguous bytes.
 template <int CO>
 __global__ __launch_bounds__(256) void deconv2d_k3s3(const float *__restrict__ x, const float *__restrict__ w,
                                                      const float *__restrict__ scale,
                                                      const float *__restrict__ shift, float *__restrict__ y,
                                                      int Cin, int Cout, int H, int W, int relu) {
     const int Wo = 3 * W, Ho = 3 * H;
-    const int xo = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y, b = blockIdx.z;
-    if (xo >= Wo) return;
-    const int xi = xo / 3, kx = xo - 3 * xi, yi = yo / 3, ky = yo - 3 * yi;
+    const int xi = blockIdx.x * 256 + threadIdx.x, yi = blockIdx.y, b = blockIdx.z;
+    if (xi >= W) return;
     const size_t plane = (size_t)H * W;
     const float *xp = x + (size_t)b * Cin * plane + (size_t)yi * W + xi;
+    float acc[3][3][CO];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[ky][kx][co] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float v = xp[(size_t)ci * plane];
+        const float *wp = w + ci * 9 * CO;                              // [ky][kx][co], wave-uniform
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[ky][kx][co] = fmaf(v, wp[(ky * 3 + kx) * CO + co], acc[ky][kx][co]);
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+        if (co < Cout) {
+            const float sc = scale[co], sh = shift[co];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float *yp = y + (((size_t)b * Cout + co) * Ho + 3 * yi + ky) * Wo + 3 * xi;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float v = fmaf(acc[ky][kx][co], sc, sh);
+                    if (relu) v = fmaxf(v, 0.f);
+                    yp[kx] = v;
+                }
+            }
+        }
+}
+
+// Conv2d k = 3, stride 3, padding 1 (the down-sampling convs of FeatExtNetChannelPlus): every input
+// pixel feeds exactly one output pixel.  A thread owns one output pixel and all CO (<= 24) output
+// channels; weights packed [Cin][3][3][CO].
+template <int CO>
+__global__ __launch_bounds__(256) void conv2d_k3s3(const float *__restrict__ x, const float *__restrict__ w,
+                                                   const float *__restrict__ scale,
+                                                   const float *__restrict__ shift, float *__restrict__ y,
+                                                   int Cin, int Cout, int H, int W, int Ho, int Wo, int relu) {
+    const int xo = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y, b = blockIdx.z;
+    if (xo >= Wo) return;
+    const size_t plane = (size_t)H * W;
+    const float *xb = x + (size_t)b * Cin * plane;
     float acc[CO];
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[co] = 0.f;
     for (int ci = 0; ci < Cin; ++ci) {
-        const float v = xp[(size_t)ci * plane];
-        const float *wp = w + ((ci * 3 + ky) * 3) * CO;                  // [ci][ky][kx][co], wave-uniform
 #pragma unroll
-        for (int co = 0; co < CO; ++co) {
-            const float w0 = wp[co], w1 = wp[CO + co], w2 = wp[2 * CO + co];
-            acc[co] = fmaf(v, kx == 0 ? w0 : kx == 1 ? w1 : w2, acc[co]);
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yi = 3 * yo - 1 + ky;
+            if ((unsigned)yi >= (unsigned)H) continue;                   // block-uniform
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(xb + (size_t)ci * plane + (size_t)yi * W), 0, W * 4, 0x00020000);
+            float v[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)               // x = -1 has a huge unsigned offset: reads as zero
+                v[kx] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (3 * xo - 1 + kx) * 4, 0, 0));
+            const float *wp = w + ((ci * 3 + ky) * 3) * CO;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] = fmaf(v[kx], wp[kx * CO + co], acc[co]);
         }
     }
 #pragma unroll
@@ -136,7 +193,7 @@ __global__ void pack_weight2d(const float *__restrict__ w, float *__restrict__ w
     wp[i] = v;
 }
 
-__host__ __device__ constexpr int co_pad(int Cout) { return Cout <= 1 ? 1 : Cout <= 4 ? 4 : 8; }
+__host__ __device__ constexpr int co_pad(int Cout) { return Cout <= 1 ? 1 : Cout <= 4 ? 4 : Cout <= 8 ? 8 : 24; }
 
 template <int CO>
 int launch_conv(const float *x, const float *w, const float *scale, const float *shift, float *y, int B,
@@ -156,7 +213,7 @@ int launch_conv(const float *x, const float *w, const float *scale, const float 
 extern "C" {
 
 size_t decnet_conv2d_packed_floats(int Cin, int Cout, int k, int transposed) {
-    if (Cin < 1 || Cout < 1 || Cout > 8 || (k != 1 && k != 3) || (transposed && k != 3)) return 0;
+    if (Cin < 1 || Cout < 1 || Cout > 24 || (k != 1 && k != 3) || (transposed && (k != 3 || Cout > 8))) return 0;
     return (size_t)Cin * k * k * (transposed ? 8 : co_pad(Cout));
 }
 
@@ -175,7 +232,7 @@ int decnet_conv2d_bn_act(const float *x, const float *w, const float *scale, con
                          void *stream) {
     if (!x || !w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
-    if ((k != 1 && k != 3) || Cout > 8 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;
+    if ((k != 1 && k != 3) || Cout > 8 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;   // (packed with co_pad(Cout) <= 8)
     if ((double)B * (Cin > Cout ? Cin : Cout) * H * W >= 9.0e18) return DECNET_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     if (Cout <= 1) return launch_conv<1>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
@@ -188,9 +245,28 @@ int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w, const float *sca
     if (!x || !w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
     if (Cout > 8 || 3 * H > 65535 || B > 65535 || 3.0 * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)ceil_div(3 * W, 256), (unsigned)(3 * H), (unsigned)B);
+    const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL((deconv2d_k3s3<8>), grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, Cin,
                        Cout, H, W, relu);
+    return decnet_launch_status();
+}
+
+int decnet_conv2d_k3s3_bn_act(const float *x, const float *w, const float *scale, const float *shift, float *y,
+                              int B, int Cin, int Cout, int H, int W, int relu, void *stream) {
+    if (!x || !w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
+    if (Cout > 24 || H > 65535 * 3 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;
+    const int Ho = (H - 1) / 3 + 1, Wo = (W - 1) / 3 + 1;            // floor((H + 2 - 3) / 3) + 1
+    const dim3 grid((unsigned)ceil_div(Wo, 256), (unsigned)Ho, (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+#define GO(N) hipLaunchKernelGGL((conv2d_k3s3<N>), grid, dim3(256), 0, s, x, w, scale, shift, y, Cin, Cout, H, W, Ho, Wo, relu)
+    switch (co_pad(Cout)) {                             // = the co pitch of the packed weights
+        case 1: GO(1); break;
+        case 4: GO(4); break;
+        case 8: GO(8); break;
+        default: GO(24); break;
+    }
+#undef GO
     return decnet_launch_status();
 }
 

@@ -46,7 +46,12 @@ class Unit(nn.Module):
             return None
         c = self.conv
         up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
-        if c.out_channels > 8 or x.shape[-1] * x.shape[-2] * up < 65536:
+        if x.shape[-1] * x.shape[-2] * up < 65536:
+            return None
+        if (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (1, 1) and
+                c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros" and c.out_channels <= 24):
+            return "conv_s3"
+        if c.out_channels > 8:
             return None
         if isinstance(c, nn.ConvTranspose2d):
             ok = (c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (0, 0) and
@@ -96,7 +101,11 @@ class Unit(nn.Module):
         Co = self.conv.out_channels
         L = _lib.lib()
         with torch.cuda.device(x.device):
-            if kind == "deconv":
+            if kind == "conv_s3":
+                y = torch.empty((B, Co, (H - 1) // 3 + 1, (W - 1) // 3 + 1), dtype=torch.float32, device=x.device)
+                rc = L.decnet_conv2d_k3s3_bn_act(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                 y.data_ptr(), B, Cin, Co, H, W, 1 if self.relu else 0, _stream(x))
+            elif kind == "deconv":
                 y = torch.empty((B, Co, 3 * H, 3 * W), dtype=torch.float32, device=x.device)
                 rc = L.decnet_deconv2d_k3s3_bn_act(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                                    y.data_ptr(), B, Cin, Co, H, W, 1 if self.relu else 0,
@@ -106,7 +115,8 @@ class Unit(nn.Module):
                 rc = L.decnet_conv2d_bn_act(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                             y.data_ptr(), B, Cin, Co, H, W, self.conv.kernel_size[0],
                                             self.conv.dilation[0], 1 if self.relu else 0, _stream(x))
-        _lib.check(rc, "decnet_conv2d_bn_act" if kind == "conv" else "decnet_deconv2d_k3s3_bn_act")
+        _lib.check(rc, {"conv": "decnet_conv2d_bn_act", "deconv": "decnet_deconv2d_k3s3_bn_act",
+                        "conv_s3": "decnet_conv2d_k3s3_bn_act"}[kind])
         return y
 
     def _folded_torch(self):

@@ -167,7 +167,8 @@ int decnet_disparity_regression(const float *cost, const float *samples, float *
  * 2-D trunk: the full-resolution, few-channel Conv2dUnit / Deconv2dUnit layers
  * (modules/submodule.py:15-87) in eval mode, conv -> BatchNorm2d(running stats) -> ReLU fused:
  *   y = act(conv(x) * scale[co] + shift[co]);  x [B,Cin,H,W], y [B,Cout,H',W'] NCHW;
- *   scale/shift: folded BN (or 1 / bias when the unit has no BN).  Cout <= 8.
+ *   scale/shift: folded BN (or 1 / bias when the unit has no BN).  Cout <= 8 (<= 24 for the
+ *   stride-3 convolution).
  * Weights are repacked once by decnet_conv2d_pack_weight into decnet_conv2d_packed_floats(...)
  * floats: torch [Cout,Cin,k,k] (transposed = 0) or ConvTranspose2d [Cin,Cout,3,3] (transposed = 1)
  * -> [Cin][k][k][co padded].
@@ -181,6 +182,11 @@ int decnet_conv2d_pack_weight(const float *w, float *w_packed, int Cin, int Cout
 int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *scale,
                          const float *shift, float *y, int B, int Cin, int Cout, int H, int W, int k, int dilation,
                          int relu, void *stream);
+/* Conv2d k = 3, stride 3, padding 1 (FeatExtNetChannelPlus down-sampling, submodule.py:245-343),
+ * Cout <= 24; y [B,Cout,(H-1)/3+1,(W-1)/3+1]; weights packed with transposed = 0. */
+int decnet_conv2d_k3s3_bn_act(const float *x, const float *w_packed, const float *scale,
+                              const float *shift, float *y, int B, int Cin, int Cout, int H, int W,
+                              int relu, void *stream);
 int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w_packed, const float *scale,
                                 const float *shift, float *y, int B, int Cin, int Cout, int H,
                                 int W, int relu, void *stream);

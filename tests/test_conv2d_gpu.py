@@ -64,8 +64,25 @@ def test_deconv_unit_vs_torch_cpu(dev, cin, cout, relu, bn):
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout", [(8, 24), (3, 8), (24, 20)])
+def test_stride3_conv_unit_vs_torch_cpu(dev, cin, cout):
+    from decnet_amd.model import Unit
+    torch.manual_seed(cin + cout)
+    u = Unit(cin, cout, 3, stride=3, pad=1).eval()
+    u.bn.weight.data.uniform_(0.5, 1.5); u.bn.bias.data.normal_(0, 0.2)
+    u.bn.running_mean.data.normal_(0, 0.2); u.bn.running_var.data.uniform_(0.5, 1.5)
+    x = torch.randn(2, cin, 271, 500, generator=torch.Generator().manual_seed(8))    # sizes not multiples of 3
+    with torch.no_grad():
+        ref = u(x)
+        ud = u.to(dev)
+        assert ud._hip_kind(x.to(dev)) == "conv_s3"
+        got = ud(x.to(dev)).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_unit_falls_back_when_not_covered(dev):
-    u = _unit(8, 24, 3).to(dev)                             # 24 output channels: MIOpen path
+    u = _unit(8, 24, 3).to(dev)                             # 24 output channels, stride 1: MIOpen path
     x = torch.randn(1, 8, 300, 300, device=dev)
     with torch.no_grad():
         assert u._hip_kind(x) is None
