@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=8)
     ap.add_argument("--mask-density", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-density-sweep", action="store_true",
+                    help="skip the extra cost-volume timings at mask densities 0.3 .. 0.02 (PMC passes: keeps "
+                         "every launch of a kernel the same work)")
     ap.add_argument("--e2e", action="store_true", help="(default at 1 GPU) see --no-e2e")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra 'e2e' object: the whole inference graph (decnet_amd.model: the 2-D "
@@ -309,7 +312,7 @@ def main():
             s3_bytes = 4.0 * B * H3 * W3 * (2 * C3 + 2 + 4)
             s3_ms = sum(e["s3_beg"].elapsed_time(e["s3_end"]) for e in ev) / args.steps
             sparse, by_density = None, []
-            if args.mask_density >= 1.0:
+            if args.mask_density >= 1.0 and not args.no_density_sweep:
                 (Lf, Rf) = hp.feats[3]
                 for dens in (0.3, 0.1, 0.05, 0.02):       # the kernel skips work ~ density^2; bytes stay whole planes
                     _, m2 = make_inputs(B, dev, dens, seed=4242)

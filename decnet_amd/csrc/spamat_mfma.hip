@@ -377,6 +377,7 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
 #else
                     // accumulate on top of the right-mask bias (0 / -1e30 per right pixel = tile row):
                     // 0 + x is exact and -1e30 + x == -1e30, so this equals adding the bias afterwards
+                    asm volatile("" ::: "memory");      // keep the 15 bias reads from being hoisted together (spills)
                     const float4 bz = *reinterpret_cast<const float4 *>(BX + (HALO + xt * 16) + 4 * q - 16 * m);
                     a4 = f32x4{bz.x, bz.y, bz.z, bz.w};
                     if (KQ) {

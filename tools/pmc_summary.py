@@ -36,7 +36,15 @@ def means(d, counter):
             names[r["Dispatch_Id"]] = r["Kernel_Name"]
         for k, v in per_dispatch.items():
             acc[names[k]].append(v)
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    # per-launch mean over the launches that did the full work: a kernel that exits at once on some
+    # launches (the marker launches of spamat_fwd_mfma behind the sparse-row kernel) would otherwise
+    # average its traffic with zeros
+    out = {}
+    for k, v in acc.items():
+        top = max(v)
+        full = [x for x in v if x >= 0.5 * top] if top > 0 else v
+        out[k] = (sum(full) / len(full), len(full))
+    return out
 
 
 def main():
@@ -47,7 +55,7 @@ def main():
            "launches": {k: v[1] for k, v in fetch.items()}}
     json.dump(raw, open(raw_out, "w"), indent=1)
     res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                   "--warmup 1 --no-cpu-baseline --no-e2e; per-launch means (tools/pmc_summary.py). FETCH_SIZE is doubled "
+                   "--warmup 1 --no-cpu-baseline --no-e2e --no-density-sweep; per-launch means (tools/pmc_summary.py). FETCH_SIZE is doubled "
                    "as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is. FETCH/WRITE are "
                    "L2<->fabric requests: Infinity-Cache hits are included, so for kernels whose working set "
                    "stays in the 256 MiB Infinity Cache this is an upper bound on HBM bytes."}
