@@ -85,7 +85,18 @@ class HotPath:
         self.reg = make_regularizer(STAGES[0][0], dev)
         self.stage0 = decnet_amd.Stage0(self.reg)
         self.outs = [tuple(torch.empty(B, H, W, device=dev) for _ in range(4)) for (_, H, W, _) in STAGES[1:]]
+        # N > 1: the all-gather of step k overlaps the kernels of step k+1, so the stage-3 outputs and
+        # the receive buffers are double buffered
+        self.outs3 = [self.outs[2], tuple(torch.empty_like(t) for t in self.outs[2])]
+        self.gbuf, self.pending, self.k = [None, None], [None, None], 0
         self.ev = None
+
+    def drain(self):
+        """Wait for the all-gathers still in flight (end of a timed region)."""
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
 
     def step(self, events=None):
         d = self.decnet
@@ -99,12 +110,20 @@ class HotPath:
             (L, R), (rm, tm) = self.feats[s], self.masks[s]
             if events is not None and s == 3:
                 events["s3_beg"].record()
-            d.spamatvar_forward(L, R, rm, tm, STAGES[s][3], out=self.outs[s - 1])
+            par = self.k & 1 if self.world > 1 else 0
+            if s == 3 and self.pending[par] is not None:     # the gather that read this buffer set two steps ago
+                self.pending[par].wait()
+                self.pending[par] = None
+            d.spamatvar_forward(L, R, rm, tm, STAGES[s][3], out=self.outs3[par] if s == 3 else self.outs[s - 1])
             if events is not None and s == 3:
                 events["s3_end"].record()
-        disp = self.outs[2][0]
-        if self.world > 1:       # one RCCL all-gather of the per-rank disparity maps
-            disp = self.dist.gather_disparity(disp, n_pairs=self.world * self.B)
+        disp = self.outs3[self.k & 1 if self.world > 1 else 0][0]
+        if self.world > 1:       # one RCCL all-gather of the per-rank disparity maps, not waited for here
+            par = self.k & 1
+            disp, self.pending[par] = self.dist.gather_disparity(disp, n_pairs=self.world * self.B,
+                                                                 out=self.gbuf[par], async_op=True)
+            self.gbuf[par] = disp
+            self.k += 1
         return pred0, disp
 
 
@@ -244,12 +263,14 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             hp.step()
+        hp.drain()
         ev = [{k: torch.cuda.Event(enable_timing=True) for k in ("s0_beg", "s0_end", "s3_beg", "s3_end")}
               for _ in range(args.steps)]
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             hp.step(ev[i])
+        hp.drain()                                      # every all-gather has landed inside the timed region
         barrier()
         elapsed = time.perf_counter() - t0
     if world > 1:

@@ -36,11 +36,16 @@ def shard_batch(tensors, rank=None, world=None):
     return cut(tensors)
 
 
-def gather_disparity(local, n_pairs=None, group=None):
+def gather_disparity(local, n_pairs=None, group=None, out=None, async_op=False):
     """All-gather per-rank disparity maps [b_r,H,W] into the global [B,H,W] on every rank
-    (rank order == pair order).  Uneven shards are padded to the largest for the collective."""
+    (rank order == pair order).  Uneven shards are padded to the largest for the collective.
+
+    ``out``: optional preallocated [world * b_max, H, W] receive buffer (reused across steps).
+    ``async_op=True`` (RCCL, even shards): returns ``(gathered, work)`` without making the current
+    stream wait -- the collective then overlaps the next batch's kernels; call ``work.wait()``
+    before reading ``gathered`` or reusing ``local`` / ``out``."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local
+        return (local, None) if async_op else local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if n_pairs is None:
@@ -57,12 +62,16 @@ def gather_disparity(local, n_pairs=None, group=None):
     if send.shape[0] < bmax:
         pad = torch.zeros((bmax - send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         send = torch.cat([send, pad], 0)
-    out = torch.empty((world * bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    shape = (world * bmax,) + tuple(send.shape[1:])
+    if out is None or tuple(out.shape) != shape or out.dtype != send.dtype or out.device != send.device:
+        out = torch.empty(shape, dtype=send.dtype, device=send.device)
+    even = all(s == bmax for s in sizes)
     if dist.get_backend(group) == "nccl":                    # RCCL
-        dist.all_gather_into_tensor(out, send, group=group)
+        work = dist.all_gather_into_tensor(out, send, group=group, async_op=bool(async_op and even))
     else:                                                    # gloo (CPU tests)
         parts = list(out.chunk(world, 0))
-        dist.all_gather(parts, send, group=group)
-    if all(s == bmax for s in sizes):
-        return out
-    return torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], 0)
+        work = dist.all_gather(parts, send, group=group, async_op=bool(async_op and even))
+    if even:
+        return (out, work) if async_op else out
+    res = torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], 0)
+    return (res, None) if async_op else res

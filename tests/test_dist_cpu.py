@@ -39,6 +39,27 @@ def _worker(rank, world, n_pairs, port, ret):
         assert torch.equal(got, full * 2 + 1), "gathered maps are not in pair order"
         got2 = gather_disparity(pred)               # sizes discovered with a small all_gather
         assert torch.equal(got2, full * 2 + 1)
+        # bench.py's N > 1 pattern: the gather of step k is waited for only when its buffers are
+        # needed again (step k + 2) -- double-buffered sources and receive buffers, async_op=True
+        if n_pairs % world == 0:
+            srcs = [torch.empty_like(local), torch.empty_like(local)]
+            gbuf, pending, seen = [None, None], [None, None], {}
+            for k in range(5):
+                par = k & 1
+                if pending[par] is not None:
+                    pending[par].wait()
+                    assert torch.equal(gbuf[par], full * (k - 2) + k - 2), "gather %d" % (k - 2)
+                    seen[k - 2] = True
+                srcs[par].copy_(local * k + k)      # "kernel" of step k
+                gbuf[par], pending[par] = gather_disparity(srcs[par], n_pairs=n_pairs, out=gbuf[par],
+                                                           async_op=True)
+            for par in (0, 1):                      # drain
+                pending[par].wait()
+            assert torch.equal(gbuf[0], full * 4 + 4) and torch.equal(gbuf[1], full * 3 + 3)
+            assert sorted(seen) == [0, 1, 2]
+        else:                                       # uneven shards: async falls back to a finished gather
+            g3, w3 = gather_disparity(pred, n_pairs=n_pairs, async_op=True)
+            assert w3 is None and torch.equal(g3, full * 2 + 1)
         ret[rank] = 1
     finally:
         dist.destroy_process_group()
