@@ -195,6 +195,28 @@ __global__ void pack_weight2d(const float *__restrict__ w, float *__restrict__ w
 
 __host__ __device__ constexpr int co_pad(int Cout) { return Cout <= 1 ? 1 : Cout <= 4 ? 4 : Cout <= 8 ? 8 : 24; }
 
+// y[b][c][:] = act(y[b][c][:] + shift[c]) in place: the folded-BatchNorm bias and the ReLU of the layers
+// that stay on MIOpen, one pass instead of a bias-add kernel and a clamp kernel.
+__global__ __launch_bounds__(256) void bias_act_inplace(float *__restrict__ y, const float *__restrict__ shift,
+                                                        int C, int HW, int relu) {
+    const int bc = blockIdx.y;                                          // b * C + c
+    const float sh = shift[bc % C];
+    float *p = y + (size_t)bc * HW;
+    const int i4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= HW) return;
+    if (i4 + 3 < HW && (((uintptr_t)(p + i4)) & 15) == 0) {
+        float4 v = *reinterpret_cast<float4 *>(p + i4);
+        v.x += sh; v.y += sh; v.z += sh; v.w += sh;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4 *>(p + i4) = v;
+    } else {
+        for (int e = 0; e < 4 && i4 + e < HW; ++e) {
+            float v = p[i4 + e] + sh;
+            p[i4 + e] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
 template <int CO>
 int launch_conv(const float *x, const float *w, const float *scale, const float *shift, float *y, int B,
                 int Cin, int Cout, int H, int W, int k, int dil, int relu, hipStream_t s) {
@@ -238,6 +260,16 @@ int decnet_conv2d_bn_act(const float *x, const float *w, const float *scale, con
     if (Cout <= 1) return launch_conv<1>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
     if (Cout <= 4) return launch_conv<4>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
     return launch_conv<8>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
+}
+
+int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu, void *stream) {
+    if (!y || !shift) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || C < 1 || H < 1 || W < 1 || (double)H * W >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
+    if ((double)B * C > 65535.0) return DECNET_ERR_UNSUPPORTED;
+    const int HW = H * W;
+    hipLaunchKernelGGL(bias_act_inplace, dim3((unsigned)ceil_div(HW, 1024), (unsigned)(B * C)), dim3(256), 0,
+                       (hipStream_t)stream, y, shift, C, HW, relu);
+    return decnet_launch_status();
 }
 
 int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w, const float *scale, const float *shift,

@@ -143,9 +143,20 @@ class Unit(nn.Module):
             w, b = self._folded_torch()
             c = self.conv
             if isinstance(c, nn.ConvTranspose2d):
-                x = F.conv_transpose2d(x, w, b, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
+                x = F.conv_transpose2d(x, w, None, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
             else:
-                x = F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
+                x = F.conv2d(x, w, None, c.stride, c.padding, c.dilation, c.groups)
+            # bias + ReLU in one in-place pass (the library would add the bias in a kernel of its own)
+            from . import _lib
+            from .ops import _stream
+            B, Co, H, W = x.shape
+            if x.is_contiguous() and B * Co <= 65535:
+                with torch.cuda.device(x.device):
+                    _lib.check(_lib.lib().decnet_bias_act_inplace(x.data_ptr(), b.data_ptr(), B, Co, H, W,
+                                                                  1 if self.relu else 0, _stream(x)),
+                               "decnet_bias_act_inplace")
+                return x
+            x = x + b.view(1, -1, 1, 1)
             return torch.relu_(x) if self.relu else x
         x = self.conv(x)
         if self.bn is not None:

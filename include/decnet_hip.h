@@ -182,6 +182,10 @@ int decnet_conv2d_pack_weight(const float *w, float *w_packed, int Cin, int Cout
 int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *scale,
                          const float *shift, float *y, int B, int Cin, int Cout, int H, int W, int k, int dilation,
                          int relu, void *stream);
+/* y[b,c,:,:] = act(y[b,c,:,:] + shift[c]) in place, y [B,C,H,W]: the folded-BatchNorm bias and the ReLU
+ * behind a library convolution, one pass.  B*C <= 65535. */
+int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu,
+                            void *stream);
 /* Conv2d k = 3, stride 3, padding 1 (FeatExtNetChannelPlus down-sampling, submodule.py:245-343),
  * Cout <= 24; y [B,Cout,(H-1)/3+1,(W-1)/3+1]; weights packed with transposed = 0. */
 int decnet_conv2d_k3s3_bn_act(const float *x, const float *w_packed, const float *scale,
