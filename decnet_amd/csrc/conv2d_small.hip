@@ -24,15 +24,23 @@ namespace {
 // (negative = huge unsigned offset) reads as zero entirely (tools/ubench/buf_oob.hip) -- so only
 // the one thread per row whose left tap straddles x = 0 patches up to three dwords; no other
 // branch or select in the loop.  Weights [Cin][K][K][CO] are wave-uniform scalar loads.
+// The input may be the channel concatenation of up to 6 tensors [B,c_i,H,W] (the torch.cat in front
+// of Deconv2dBlock / Refinement / SoftAttention convolutions is never materialised).
+constexpr int MAXSEG = 6;
+struct Segs {
+    const float *p[MAXSEG];
+    int c[MAXSEG];
+    int n;
+};
+
 template <int CO, int K>
-__global__ __launch_bounds__(256) void conv2d_small(const float *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__restrict__ w,
                                                     const float *__restrict__ scale,
                                                     const float *__restrict__ shift, float *__restrict__ y,
-                                                    int Cin, int Cout, int H, int W, int dil, int relu) {
+                                                    int Cout, int H, int W, int dil, int relu) {
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, yy = blockIdx.y, b = blockIdx.z;
     if (x0 >= W) return;
     const size_t plane = (size_t)H * W;
-    const float *xb = x + (size_t)b * Cin * plane;
     const int xl = x0 - (K / 2) * dil;                                   // first element of the left tap
     const bool straddle = xl < 0 && xl > -4;
     float acc[CO][4];
@@ -40,8 +48,10 @@ __global__ __launch_bounds__(256) void conv2d_small(const float *__restrict__ x,
     for (int co = 0; co < CO; ++co)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[co][e] = 0.f;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float *xp = xb + (size_t)ci * plane;
+    int ci = 0;                                                          // channel of the concatenation
+    for (int sg = 0; sg < in.n; ++sg)
+    for (int cs = 0; cs < in.c[sg]; ++cs, ++ci) {
+        const float *xp = in.p[sg] + ((size_t)b * in.c[sg] + cs) * plane;
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
             const int yi = yy + (ky - K / 2) * dil;
@@ -218,16 +228,50 @@ __global__ __launch_bounds__(256) void bias_act_inplace(float *__restrict__ y, c
 }
 
 template <int CO>
-int launch_conv(const float *x, const float *w, const float *scale, const float *shift, float *y, int B,
-                int Cin, int Cout, int H, int W, int k, int dil, int relu, hipStream_t s) {
+int launch_conv(const Segs &in, const float *w, const float *scale, const float *shift, float *y, int B,
+                int Cout, int H, int W, int k, int dil, int relu, hipStream_t s) {
     const dim3 grid((unsigned)ceil_div(W, 1024), (unsigned)H, (unsigned)B);
     if (k == 3)
-        hipLaunchKernelGGL((conv2d_small<CO, 3>), grid, dim3(256), 0, s, x, w, scale, shift, y, Cin, Cout, H, W,
-                           dil, relu);
+        hipLaunchKernelGGL((conv2d_small<CO, 3>), grid, dim3(256), 0, s, in, w, scale, shift, y, Cout, H, W, dil,
+                           relu);
     else
-        hipLaunchKernelGGL((conv2d_small<CO, 1>), grid, dim3(256), 0, s, x, w, scale, shift, y, Cin, Cout, H, W,
-                           dil, relu);
+        hipLaunchKernelGGL((conv2d_small<CO, 1>), grid, dim3(256), 0, s, in, w, scale, shift, y, Cout, H, W, dil,
+                           relu);
     return decnet_launch_status();
+}
+
+// grid_sample(right, (x - disp) stretched as submodule.py:719-745) -- the warp of Refinement: per-pixel
+// disparity, align_corners=False sampling of align_corners=True-normalised coordinates,
+// bilinear, zero padding; the arithmetic follows torch's grid_sampler (weights as products of
+// differences, taps added in the order nw, ne, sw, se).
+__global__ __launch_bounds__(256) void warp_disparity(const float *__restrict__ right,
+                                                      const float *__restrict__ disp, float *__restrict__ out,
+                                                      int C, int H, int W) {
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const size_t plane = (size_t)H * W;
+    const float d = disp[(size_t)b * plane + (size_t)y * W + x];
+    const float cx = ((float)x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
+    const float cy = (float)y / ((float)(H - 1.0) / 2.0f) - 1.0f;
+    const float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float nw = (fx + 1.0f - ix) * (fy + 1.0f - iy), ne = (ix - fx) * (fy + 1.0f - iy);
+    const float sw = (fx + 1.0f - ix) * (iy - fy), se = (ix - fx) * (iy - fy);
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
+    const float *rb = right + (size_t)b * C * plane;
+    float *ob = out + (size_t)b * C * plane + (size_t)y * W + x;
+    for (int c = 0; c < C; ++c) {
+        const float *rp = rb + (size_t)c * plane;
+        float v = 0.f;
+        if (vy0 && vx0) v += rp[(size_t)y0 * W + x0] * nw;
+        if (vy0 && vx1) v += rp[(size_t)y0 * W + x1] * ne;
+        if (vy1 && vx0) v += rp[(size_t)y1 * W + x0] * sw;
+        if (vy1 && vx1) v += rp[(size_t)y1 * W + x1] * se;
+        ob[(size_t)c * plane] = v;
+    }
 }
 
 }  // namespace
@@ -249,17 +293,51 @@ int decnet_conv2d_pack_weight(const float *w, float *w_packed, int Cin, int Cout
     return decnet_launch_status();
 }
 
+static int conv2d_segs(const Segs &in, const float *w, const float *scale, const float *shift, float *y, int B,
+                       int Cout, int H, int W, int k, int dilation, int relu, void *stream) {
+    if (!w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
+    if ((k != 1 && k != 3) || Cout > 8 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;
+    int cin = 0;
+    for (int i = 0; i < in.n; ++i) {
+        if (!in.p[i]) return DECNET_ERR_NULL_POINTER;
+        if (in.c[i] < 1) return DECNET_ERR_BAD_SHAPE;
+        cin += in.c[i];
+    }
+    if ((double)B * (cin > Cout ? cin : Cout) * H * W >= 9.0e18) return DECNET_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 1) return launch_conv<1>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
+    if (Cout <= 4) return launch_conv<4>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
+    return launch_conv<8>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
+}
+
 int decnet_conv2d_bn_act(const float *x, const float *w, const float *scale, const float *shift, float *y,
                          int B, int Cin, int Cout, int H, int W, int k, int dilation, int relu,
                          void *stream) {
-    if (!x || !w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
-    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
-    if ((k != 1 && k != 3) || Cout > 8 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;   // (packed with co_pad(Cout) <= 8)
-    if ((double)B * (Cin > Cout ? Cin : Cout) * H * W >= 9.0e18) return DECNET_ERR_BAD_SHAPE;
-    hipStream_t s = (hipStream_t)stream;
-    if (Cout <= 1) return launch_conv<1>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
-    if (Cout <= 4) return launch_conv<4>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
-    return launch_conv<8>(x, w, scale, shift, y, B, Cin, Cout, H, W, k, dilation, relu, s);
+    Segs in{};
+    in.p[0] = x; in.c[0] = Cin; in.n = 1;
+    return conv2d_segs(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, stream);
+}
+
+int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, const float *w,
+                             const float *scale, const float *shift, float *y, int B, int Cout, int H, int W,
+                             int k, int dilation, int relu, void *stream) {
+    if (!xs || !cins) return DECNET_ERR_NULL_POINTER;
+    if (nseg < 1 || nseg > MAXSEG) return DECNET_ERR_UNSUPPORTED;
+    Segs in{};
+    for (int i = 0; i < nseg; ++i) { in.p[i] = xs[i]; in.c[i] = cins[i]; }
+    in.n = nseg;
+    return conv2d_segs(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, stream);
+}
+
+int decnet_warp_disparity(const float *right, const float *disp, float *out, int B, int C, int H, int W,
+                          void *stream) {
+    if (!right || !disp || !out) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || C < 1 || H < 2 || W < 2) return DECNET_ERR_BAD_SHAPE;
+    if (H > 65535 || B > 65535) return DECNET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(warp_disparity, dim3((unsigned)ceil_div(W, 256), (unsigned)H, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, right, disp, out, C, H, W);
+    return decnet_launch_status();
 }
 
 int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu, void *stream) {

@@ -38,8 +38,15 @@ class Unit(nn.Module):
 
     # ---- fused HIP path for the full-resolution few-channel layers (csrc/conv2d_small.hip) ----
     def _hip_kind(self, x):
-        """"conv" / "deconv" when this unit, in eval mode on the GPU, is one the small-channel kernels
-        cover (they pay off where the tensors are large: >= 64 k pixels per image); else None."""
+        """"conv" / "deconv" / "conv_s3" when this unit, in eval mode on the GPU, is one the
+        small-channel kernels cover (they pay off where the tensors are large: >= 64 k pixels per
+        image); else None.  x: a tensor, or a tuple of tensors standing for their channel concatenation."""
+        if isinstance(x, (tuple, list)):
+            if (len(x) > 6 or any(t.shape[0] != x[0].shape[0] or t.shape[2:] != x[0].shape[2:] or t.dtype != x[0].dtype
+                                  or t.device != x[0].device for t in x)):
+                return None
+            kind = self._hip_kind(x[0])
+            return kind if kind == "conv" else None
         if self.training or not x.is_cuda or x.dtype != torch.float32 or torch.is_grad_enabled():
             return None
         if os.environ.get("DECNET_CONV2D", "hip") != "hip":
@@ -95,8 +102,24 @@ class Unit(nn.Module):
     def _forward_hip(self, x, kind):
         from . import _lib
         from .ops import _stream
-        x = x.contiguous()
         w, scale, shift = self._folded()
+        if isinstance(x, (tuple, list)):                # concatenated input, never materialised
+            import ctypes
+            xs = [t.contiguous() for t in x]
+            B, _, H, W = xs[0].shape
+            Co = self.conv.out_channels
+            assert sum(t.shape[1] for t in xs) == self.conv.in_channels
+            y = torch.empty((B, Co, H, W), dtype=torch.float32, device=xs[0].device)
+            ptrs = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+            cins = (ctypes.c_int * len(xs))(*[int(t.shape[1]) for t in xs])
+            with torch.cuda.device(y.device):
+                rc = _lib.lib().decnet_conv2d_cat_bn_act(ptrs, cins, len(xs), w.data_ptr(), scale.data_ptr(),
+                                                         shift.data_ptr(), y.data_ptr(), B, Co, H, W,
+                                                         self.conv.kernel_size[0], self.conv.dilation[0],
+                                                         1 if self.relu else 0, _stream(y))
+            _lib.check(rc, "decnet_conv2d_cat_bn_act")
+            return y
+        x = x.contiguous()
         B, Cin, H, W = x.shape
         Co = self.conv.out_channels
         L = _lib.lib()
@@ -138,6 +161,8 @@ class Unit(nn.Module):
         kind = self._hip_kind(x)
         if kind is not None:
             return self._forward_hip(x, kind)
+        if isinstance(x, (tuple, list)):
+            x = torch.cat(tuple(x), 1)
         if (self.bn is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda and
                 os.environ.get("DECNET_FOLD_BN", "1") == "1"):
             w, b = self._folded_torch()
@@ -182,7 +207,7 @@ class UpBlock(nn.Module):
 
     def forward(self, skip, x):
         up = self.deconv(x)
-        return self.conv(torch.cat((up, skip), 1)), up
+        return self.conv((up, skip)), up                # Unit takes the concatenation as a tuple
 
 
 class ASPP(nn.Module):
@@ -289,6 +314,16 @@ def warp_by_disparity(right, disp):
     """Refinement.get_warped_feats_by_homgrp (submodule.py:719-745): the same stretched,
     half-pixel-shifted bilinear warp as stage 0, one disparity per pixel."""
     B, C, H, W = right.shape
+    if (right.is_cuda and right.dtype == torch.float32 and not torch.is_grad_enabled() and H > 1 and W > 1 and
+            H <= 65535 and os.environ.get("DECNET_CONV2D", "hip") == "hip"):
+        from . import _lib
+        from .ops import _stream
+        r, d = right.contiguous(), disp.contiguous()
+        out = torch.empty_like(r)
+        with torch.cuda.device(r.device):
+            _lib.check(_lib.lib().decnet_warp_disparity(r.data_ptr(), d.data_ptr(), out.data_ptr(), B, C, H, W,
+                                                        _stream(r)), "decnet_warp_disparity")
+        return out
     ys, xs = torch.meshgrid(torch.arange(H, dtype=right.dtype, device=right.device),
                             torch.arange(W, dtype=right.dtype, device=right.device), indexing="ij")
     cx = (xs.unsqueeze(0) - disp) / ((W - 1.0) / 2.0) - 1.0
@@ -310,7 +345,7 @@ class Refinement(nn.Module):
                          _c3(h, 1, relu=False, bn=False))
 
     def forward(self, left, right, disp):
-        res = self.conv(torch.cat((left, warp_by_disparity(right, disp), disp.unsqueeze(1)), 1)).squeeze(1)
+        res = self.conv((left, warp_by_disparity(right, disp), disp.unsqueeze(1))).squeeze(1)
         return disp + res, res
 
 
@@ -372,8 +407,8 @@ class SparseDenseNetRefinementMask(nn.Module):
             # SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch
             sparse, var, _, _ = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(),
                                                   rmask.contiguous(), cur_max_disp)
-            soft = self.soft_attention[stage - 1](torch.cat(
-                (L, dense.unsqueeze(1), sparse.unsqueeze(1), lmask.unsqueeze(1), -var.unsqueeze(1)), 1)).squeeze(1)
+            soft = self.soft_attention[stage - 1](
+                (L, dense.unsqueeze(1), sparse.unsqueeze(1), lmask.unsqueeze(1), -var.unsqueeze(1))).squeeze(1)
             fused = dense * (1 - soft) + soft * sparse                    # reference :202
             pred, _ = self.refinement[stage - 1](L, R, fused)             # reference :207
         return [pred]

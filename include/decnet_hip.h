@@ -182,6 +182,17 @@ int decnet_conv2d_pack_weight(const float *w, float *w_packed, int Cin, int Cout
 int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *scale,
                          const float *shift, float *y, int B, int Cin, int Cout, int H, int W, int k, int dilation,
                          int relu, void *stream);
+/* decnet_conv2d_bn_act on the channel concatenation of nseg (<= 6) tensors xs[i] [B,cins[i],H,W]
+ * (host arrays of device pointers / channel counts; weights packed for Cin = sum of cins): the
+ * torch.cat in front of the Deconv2dBlock / Refinement / SoftAttention convolutions
+ * (submodule.py:176, 755, SparseDenseNetRefinementMask.py:195-199) is never materialised. */
+int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, const float *w_packed,
+                             const float *scale, const float *shift, float *y, int B, int Cout, int H,
+                             int W, int k, int dilation, int relu, void *stream);
+/* Refinement.get_warped_feats_by_homgrp (submodule.py:719-745): out[b,c,y,x] = bilinear(right[b,c];
+ * (x - disp[b,y,x]) * W/(W-1) - 0.5, y * H/(H-1) - 0.5), zero padding.  right,out [B,C,H,W], disp [B,H,W]. */
+int decnet_warp_disparity(const float *right, const float *disp, float *out, int B, int C, int H, int W,
+                          void *stream);
 /* y[b,c,:,:] = act(y[b,c,:,:] + shift[c]) in place, y [B,C,H,W]: the folded-BatchNorm bias and the ReLU
  * behind a library convolution, one pass.  B*C <= 65535. */
 int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu,

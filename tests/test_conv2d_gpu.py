@@ -81,6 +81,27 @@ def test_stride3_conv_unit_vs_torch_cpu(dev, cin, cout):
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+def test_concatenated_input_and_warp(dev):
+    """Unit on a tuple == Unit on torch.cat; warp_by_disparity kernel == the torch grid_sample path."""
+    from decnet_amd import model as M
+    u = _unit(17, 8, 3, dil=3, seed=3)
+    g = torch.Generator().manual_seed(12)
+    a, b, c = (torch.randn(2, n, 140, 500, generator=g) for n in (8, 8, 1))
+    with torch.no_grad():
+        ref = u(torch.cat((a, b, c), 1))
+        ud = u.to(dev)
+        parts = (a.to(dev), b.to(dev), c.to(dev))
+        assert ud._hip_kind(parts) == "conv"
+        got = ud(parts).cpu()
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    right = torch.randn(2, 8, 140, 500, generator=g)
+    disp = torch.rand(2, 140, 500, generator=g) * 60 - 5          # some samples fall outside the image
+    with torch.no_grad():
+        ref = M.warp_by_disparity(right, disp)                     # CPU: meshgrid + grid_sample
+        got = M.warp_by_disparity(right.to(dev), disp.to(dev)).cpu()
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_unit_falls_back_when_not_covered(dev):
     u = _unit(8, 24, 3).to(dev)                             # 24 output channels, stride 1: MIOpen path
     x = torch.randn(1, 8, 300, 300, device=dev)
