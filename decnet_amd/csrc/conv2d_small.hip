@@ -293,6 +293,48 @@ int decnet_conv2d_pack_weight(const float *w, float *w_packed, int Cin, int Cout
     return decnet_launch_status();
 }
 
+// Tail of DynamicUpsampling.forward (submodule.py:566-589) for down_scale 3: per coarse pixel, nine
+// softmaxes over the 3x3 neighbourhood (logits [B,81,h,w]: channel = 9 * sub-position + neighbour) weight
+// the replicate-padded neighbours of the coarse disparity; pixel_shuffle and the x3 are the store
+// pattern.  One pass over the logits instead of softmax / multiply / sum / pixel_shuffle / scale kernels.
+__global__ __launch_bounds__(256) void dynamic_upsample3(const float *__restrict__ logits,
+                                                         const float *__restrict__ disp, float *__restrict__ out,
+                                                         int h, int w) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= w) return;
+    const size_t plane = (size_t)h * w;
+    const float *dp = disp + (size_t)b * plane;
+    float nb[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = min(max(y + ky - 1, 0), h - 1), xx = min(max(x + kx - 1, 0), w - 1);   // ReplicationPad2d(1)
+            nb[ky * 3 + kx] = dp[(size_t)yy * w + xx];
+        }
+    const float *lp = logits + (size_t)b * 81 * plane + (size_t)y * w + x;
+    float *op = out + ((size_t)b * 3 * h + 3 * y) * (3 * (size_t)w) + 3 * x;
+#pragma unroll
+    for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+            float v[9], m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                v[k] = lp[(size_t)((sy * 3 + sx) * 9 + k) * plane];
+                m = fmaxf(m, v[k]);
+            }
+            float sum = 0.f, acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float e = expf(v[k] - m);
+                sum += e;
+                acc = fmaf(e, nb[k], acc);
+            }
+            op[(size_t)sy * 3 * w + sx] = acc / sum * 3.0f;
+        }
+}
+
 static int conv2d_segs(const Segs &in, const float *w, const float *scale, const float *shift, float *y, int B,
                        int Cout, int H, int W, int k, int dilation, int relu, void *stream) {
     if (!w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
@@ -328,6 +370,16 @@ int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, 
     for (int i = 0; i < nseg; ++i) { in.p[i] = xs[i]; in.c[i] = cins[i]; }
     in.n = nseg;
     return conv2d_segs(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, stream);
+}
+
+int decnet_dynamic_upsample3(const float *logits, const float *disp, float *out, int B, int h, int w,
+                             void *stream) {
+    if (!logits || !disp || !out) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || h < 1 || w < 1) return DECNET_ERR_BAD_SHAPE;
+    if (h > 65535 || B > 65535) return DECNET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dynamic_upsample3, dim3((unsigned)ceil_div(w, 256), (unsigned)h, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, logits, disp, out, h, w);
+    return decnet_launch_status();
 }
 
 int decnet_warp_disparity(const float *right, const float *disp, float *out, int B, int C, int H, int W,

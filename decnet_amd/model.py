@@ -292,7 +292,18 @@ class DynamicUpsampling(nn.Module):
         B, h, w = disp.shape
         s2 = self.s ** 2
         wts = torch.cat((disp.unsqueeze(1), F.unfold(fea, self.s, stride=self.s).view(B, -1, h, w)), 1)
-        wts = F.softmax(self.weight_learning(wts).view(B, s2, 9, h * w), 2)
+        logits = self.weight_learning(wts)
+        if (self.s == 3 and logits.is_cuda and logits.dtype == torch.float32 and not torch.is_grad_enabled() and
+                h <= 65535 and os.environ.get("DECNET_CONV2D", "hip") == "hip"):
+            from . import _lib
+            from .ops import _stream
+            lg, dp = logits.contiguous(), disp.contiguous()
+            out = torch.empty((B, 3 * h, 3 * w), dtype=torch.float32, device=lg.device)
+            with torch.cuda.device(lg.device):
+                _lib.check(_lib.lib().decnet_dynamic_upsample3(lg.data_ptr(), dp.data_ptr(), out.data_ptr(), B, h, w,
+                                                               _stream(lg)), "decnet_dynamic_upsample3")
+            return out
+        wts = F.softmax(logits.view(B, s2, 9, h * w), 2)
         nb = F.unfold(self.pad(disp.unsqueeze(1)), 3).unsqueeze(1)
         up = (nb * wts).sum(2).view(B, s2, h, w)
         return (F.pixel_shuffle(up, self.s) * self.s).squeeze(1)

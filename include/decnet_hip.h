@@ -193,6 +193,11 @@ int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, 
  * (x - disp[b,y,x]) * W/(W-1) - 0.5, y * H/(H-1) - 0.5), zero padding.  right,out [B,C,H,W], disp [B,H,W]. */
 int decnet_warp_disparity(const float *right, const float *disp, float *out, int B, int C, int H, int W,
                           void *stream);
+/* Tail of DynamicUpsampling.forward (submodule.py:581-589), down_scale 3: logits [B,81,h,w] (channel =
+ * 9 * sub-position + neighbour), disp [B,h,w] -> out [B,3h,3w] =
+ * 3 * pixel_shuffle(sum_k softmax_k(logits) * replicate-padded 3x3 neighbours of disp). */
+int decnet_dynamic_upsample3(const float *logits, const float *disp, float *out, int B, int h, int w,
+                             void *stream);
 /* y[b,c,:,:] = act(y[b,c,:,:] + shift[c]) in place, y [B,C,H,W]: the folded-BatchNorm bias and the ReLU
  * behind a library convolution, one pass.  B*C <= 65535. */
 int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu,

@@ -102,6 +102,20 @@ def test_concatenated_input_and_warp(dev):
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+def test_dynamic_upsampling_tail_kernel(dev):
+    """DynamicUpsampling on the GPU (fused tail kernel) == the torch ops on CPU."""
+    from decnet_amd.model import DynamicUpsampling
+    torch.manual_seed(4)
+    m = DynamicUpsampling(8, 3).eval()
+    g = torch.Generator().manual_seed(14)
+    disp, fea = torch.rand(2, 37, 45, generator=g) * 20, torch.randn(2, 8, 111, 135, generator=g)
+    with torch.no_grad():
+        ref = m(disp, fea)
+        got = m.to(dev)(disp.to(dev), fea.to(dev)).cpu()
+    assert got.shape == ref.shape == (2, 111, 135)
+    assert float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_unit_falls_back_when_not_covered(dev):
     u = _unit(8, 24, 3).to(dev)                             # 24 output channels, stride 1: MIOpen path
     x = torch.randn(1, 8, 300, 300, device=dev)
