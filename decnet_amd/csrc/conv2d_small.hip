@@ -339,7 +339,7 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
                        int Cout, int H, int W, int k, int dilation, int relu, void *stream) {
     if (!w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
-    if ((k != 1 && k != 3) || Cout > 8 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;
+    if ((k != 1 && k != 3) || Cout > 24 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;
     int cin = 0;
     for (int i = 0; i < in.n; ++i) {
         if (!in.p[i]) return DECNET_ERR_NULL_POINTER;
@@ -350,7 +350,8 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
     hipStream_t s = (hipStream_t)stream;
     if (Cout <= 1) return launch_conv<1>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
     if (Cout <= 4) return launch_conv<4>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
-    return launch_conv<8>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
+    if (Cout <= 8) return launch_conv<8>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
+    return launch_conv<24>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);   // co_pad(Cout) = 24
 }
 
 int decnet_conv2d_bn_act(const float *x, const float *w, const float *scale, const float *shift, float *y,

@@ -53,12 +53,14 @@ class Unit(nn.Module):
             return None
         c = self.conv
         up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
-        if x.shape[-1] * x.shape[-2] * up < 65536:
+        if x.shape[-1] * x.shape[-2] * up < 16384:
             return None
         if (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (1, 1) and
                 c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros" and c.out_channels <= 24):
             return "conv_s3"
-        if c.out_channels > 8:
+        tr = isinstance(c, nn.ConvTranspose2d)
+        # 9..24 output channels: only where the library is slow (dilated taps) or the input is thin
+        if c.out_channels > (8 if tr else 24) or (c.out_channels > 8 and c.dilation[0] == 1 and c.in_channels > 12):
             return None
         if isinstance(c, nn.ConvTranspose2d):
             ok = (c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (0, 0) and

@@ -167,8 +167,8 @@ int decnet_disparity_regression(const float *cost, const float *samples, float *
  * 2-D trunk: the full-resolution, few-channel Conv2dUnit / Deconv2dUnit layers
  * (modules/submodule.py:15-87) in eval mode, conv -> BatchNorm2d(running stats) -> ReLU fused:
  *   y = act(conv(x) * scale[co] + shift[co]);  x [B,Cin,H,W], y [B,Cout,H',W'] NCHW;
- *   scale/shift: folded BN (or 1 / bias when the unit has no BN).  Cout <= 8 (<= 24 for the
- *   stride-3 convolution).
+ *   scale/shift: folded BN (or 1 / bias when the unit has no BN).  Cout <= 24 (<= 8 for the
+ *   transposed convolution).
  * Weights are repacked once by decnet_conv2d_pack_weight into decnet_conv2d_packed_floats(...)
  * floats: torch [Cout,Cin,k,k] (transposed = 0) or ConvTranspose2d [Cin,Cout,3,3] (transposed = 1)
  * -> [Cin][k][k][co padded].

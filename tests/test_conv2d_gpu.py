@@ -32,7 +32,8 @@ def _unit(cin, cout, k, dil=1, relu=True, bn=True, transposed=False, seed=0):
 @pytest.mark.parametrize("cin,cout,k,dil,relu,bn", [
     (8, 8, 3, 1, True, True), (17, 8, 3, 3, True, True), (8, 8, 3, 6, True, True), (4, 4, 3, 9, True, True),
     (3, 8, 3, 1, True, True), (8, 3, 3, 1, False, True), (8, 1, 3, 1, False, False), (4, 1, 3, 1, False, False),
-    (8, 8, 1, 1, True, True), (16, 8, 3, 1, True, True), (3, 1, 1, 1, False, True)])
+    (8, 8, 1, 1, True, True), (16, 8, 3, 1, True, True), (3, 1, 1, 1, False, True),
+    (49, 24, 3, 2, True, True), (24, 24, 3, 4, True, True), (12, 12, 3, 6, True, True), (8, 24, 3, 1, True, True)])
 def test_conv_unit_vs_torch_cpu(dev, cin, cout, k, dil, relu, bn):
     u = _unit(cin, cout, k, dil, relu, bn, seed=cin * 31 + cout)
     g = torch.Generator().manual_seed(5)
@@ -117,8 +118,8 @@ def test_dynamic_upsampling_tail_kernel(dev):
 
 
 def test_unit_falls_back_when_not_covered(dev):
-    u = _unit(8, 24, 3).to(dev)                             # 24 output channels, stride 1: MIOpen path
-    x = torch.randn(1, 8, 300, 300, device=dev)
+    u = _unit(24, 24, 3).to(dev)                            # 24 -> 24 channels, no dilation: MIOpen path
+    x = torch.randn(1, 24, 300, 300, device=dev)
     with torch.no_grad():
         assert u._hip_kind(x) is None
         assert tuple(u(x).shape) == (1, 24, 300, 300)

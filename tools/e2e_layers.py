@@ -30,7 +30,9 @@ def main():
         def f(m, inp):
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            state[name] = (e, tuple(inp[0].shape))
+            x = inp[0]
+            shp = tuple(x.shape) if torch.is_tensor(x) else ("cat",) + tuple(tuple(t.shape) for t in x)
+            state[name] = (e, shp)
         return f
 
     def post(name):
