@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void cout1_gather_softargmax(const float *__re
         if (reg) reg[(((size_t)b * D + d) * H + yy) * W + xx] = cost;
     }
     __syncthreads();
-    if (threadIdx.x < PB && blockIdx.x * PB + threadIdx.x < npix) {
+    if ((int)threadIdx.x < PB && (int)(blockIdx.x * PB + threadIdx.x) < npix) {
         float m = -INFINITY, S = 0.f, Tt = 0.f;
         for (int dd = 0; dd < D; ++dd) {
             const float cost = costs[threadIdx.x * D + dd];

@@ -1,10 +1,8 @@
 """Parity of the fused small-channel Conv2dUnit / Deconv2dUnit kernels (csrc/conv2d_small.hip) with
 torch CPU conv2d -> batch_norm(eval) -> relu (the third-party arithmetic the reference calls,
 modules/submodule.py:15-87).  -m gpu.  Tolerance: 2e-5 * max|y| (fp32, different summation order)."""
-import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
