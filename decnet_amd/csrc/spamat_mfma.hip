@@ -117,11 +117,11 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
     // COMPACT: the right positions are re-read from LDS in every pass through a pointer the
     // compiler cannot identify with the previous pass's (otherwise GVN keeps all 4*NTL of them
     // live across the passes and the kernel spills)
-    // (LDS word offsets, made opaque per pass: see the COMPACT note above and pass 1's bias)
-    int xo1 = xr_off, bo1 = bias_off;
-    asm volatile("" : "+v"(xo1), "+v"(bo1));
+    // (LDS word offsets, made opaque per pass: see the COMPACT note above)
+    (void)bias_off;                 // the dense path's right-mask bias is the MFMAs' initial accumulator
+    int xo1 = xr_off;
+    asm volatile("" : "+v"(xo1));
     const int *xp1 = reinterpret_cast<const int *>(lds) + xo1;
-    const float *bp1 = lds + bo1;
 #pragma unroll
     for (int m = 0; m < NTL; ++m) {
         if (m < ntile) {
