@@ -45,6 +45,7 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int W_BN = 224;      // co rows of U^T per transform point: 14 MFMA tiles of 16
+__host__ __device__ constexpr int pad16(int c) { return (c + 15) & ~15; }
 
 // 1-D transforms of F(m,3), m = O outputs, tile T = O + 2 (Lavin & Gray, arXiv:1509.09308)
 template <int T> __device__ __forceinline__ void bt_1d(float (&v)[T]);
@@ -494,6 +495,173 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
     wino_gemm_wave<NFULL, TAIL, 3>(Vb, Ub, Mb, nt, Ci, Co, xg, np, pg * xg, (mb * WM + wm) * 48, wn);
 }
 
+// ------------------------------ the same GEMM on the bf16 matrix cores, fp32 accurate ------------
+// DECNET_WINO_GEMM=bf16x3 (experimental).  tools/ubench/mfma_rate.hip: v_mfma_f32_16x16x4_f32 issues
+// every ~35 cycles, v_mfma_f32_16x16x32_bf16 every ~18.  Each fp32 operand is split into three bf16
+// terms x = hi + mid + lo (truncations with exact residuals, 24 mantissa bits together) and the six
+// products above 2^-24 are accumulated in fp32:
+//     u*v ~ uh*vh + uh*vm + um*vh + uh*vl + um*vm + ul*vh        (dropped: um*vl, ul*vm, ul*vl)
+// i.e. 6 x 18 MFMA cycles per 32 k instead of 8 x 35.  U^T is split once at weight-packing time
+// ([point][pair of 16-chunks][term][224 co][4 kq][8 bf16]: a wave's operand load stays 1 KiB
+// contiguous), V is split in registers.  Two waves per SIMD: the U^T terms stream through a ring of
+// four operand tiles (three tiles = ~1000 MFMA cycles ahead), the fp32 V of the next pair is in
+// flight during the whole current pair.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(const f32x4 &a, const f32x4 &b, i32x4 &hi, i32x4 &mid, i32x4 &lo) {
+    // 8 values (a: chunk 2p, b: chunk 2p+1) -> three packed 8 x bf16 operands
+    float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    int h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = __float_as_int(x[e]) & 0xffff0000;
+        const float r1 = x[e] - __int_as_float(h[e]);
+        m[e] = __float_as_int(r1) & 0xffff0000;
+        l[e] = __float_as_int(r1 - __int_as_float(m[e]));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                       // {x[2e+1][31:16], x[2e][31:16]}
+        hi[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302);
+        mid[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302);
+        lo[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302);
+    }
+}
+
+// fp32 U^T [point][kc][224][16] -> bf16 terms [point][pair][term][224][kq][8]
+__global__ void wino_split_weights(const float *__restrict__ U, int *__restrict__ Ub, int np, int KC, int Ci) {
+    const int NP2 = (KC + 1) / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // (point, pair, co, kq)
+    if (idx >= np * NP2 * W_BN * 4) return;
+    const int kq = idx & 3, co = (idx >> 2) % W_BN, pp = (idx >> 2) / W_BN;
+    const int pair = pp % NP2, pt = pp / NP2;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    const float *u0 = U + (((size_t)pt * KC + 2 * pair) * W_BN + co) * 16 + 4 * kq;
+    // k slots >= Ci of the last chunk are never written in the fp32 layout: zeros here
+    if (32 * pair + 4 * kq < Ci) a = *reinterpret_cast<const f32x4 *>(u0);
+    if (2 * pair + 1 < KC && 32 * pair + 16 + 4 * kq < Ci) b = *reinterpret_cast<const f32x4 *>(u0 + (size_t)W_BN * 16);
+    i32x4 t[3];
+    split3(a, b, t[0], t[1], t[2]);
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+        *reinterpret_cast<i32x4 *>(Ub + ((((size_t)pt * NP2 + pair) * 3 + term) * W_BN + co) * 16 + 4 * kq) = t[term];
+}
+
+template <int WM, int NPAIR>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_bf16x3(
+    const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
+    int Co, int np, int swz) {
+    constexpr int TM = 3, TN = 7, OOB = 0x7fffffff, RING = 4, AHEAD = 3;
+    const int mblocks = gridDim.x, ngroups = gridDim.y;
+    int pt = blockIdx.y, mb = blockIdx.x;
+    if (swz) {
+        const int id = blockIdx.y * mblocks + blockIdx.x, per8 = 8 * mblocks;
+        const int r = id / per8, q = id - r * per8;
+        if (8 * (r + 1) <= ngroups) { pt = 8 * r + (q & 7); mb = q >> 3; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, kq = lane >> 4;
+    const int m0 = (mb * WM + wm) * 48;
+    if (m0 >= nt) return;
+    const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;
+    const int v_chunk = nt * 64, v_point = KC * v_chunk, m_point = CG * v_chunk;
+    const int u_term = W_BN * 64, u_pair = 3 * u_term, u_point = NPAIR * u_pair;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * v_point, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ubb, 0, np * u_point, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * m_point, 0x00020000);
+    int v_row[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + i * 16 + i16;
+        v_row[i] = m < nt ? m * 64 : OOB;
+    }
+    const int u_lane = (wn * (W_BN / 2) + i16) * 64 + kq * 16 + pt * u_point;
+
+    // operand tiles are consumed in the order s = pair * 7 + j; the three bf16 terms of tile s + AHEAD
+    // are in flight while tile s is multiplied (ring of 4 x 12 registers), the fp32 V of the next pair
+    // during the whole current pair
+    f32x4 vf[TM][2];
+    i32x4 ub[RING][3], vs[TM][3];
+    auto load_u = [&](int slot, int s) {
+        const int p = s / TN, j = s - p * TN;
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+            ub[slot][term] = __builtin_amdgcn_raw_buffer_load_b128(
+                ur, p < NPAIR ? u_lane + p * u_pair + term * u_term + j * 1024 : OOB, 0, 0);
+    };
+    auto load_v = [&](int p) {
+        const int vb = pt * v_point + kq * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = 2 * p + h;
+                const bool ok = p < NPAIR && v_row[i] != OOB && c * 16 + kq * 4 < Ci;   // whole 16-byte groups
+                const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(vr, ok ? v_row[i] + vb + c * v_chunk : OOB, 0, 0);
+                vf[i][h] = f32x4{__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w)};
+            }
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (u term, v term): the six products above 2^-24, small ones first
+    constexpr int UT[6] = {2, 1, 0, 1, 0, 0}, VT[6] = {0, 1, 2, 0, 1, 0};
+
+    load_v(0);
+    load_u(0, 0);
+    load_u(1, 1);
+    // operand tiles two at a time (six independent accumulators between two MFMAs on the same one);
+    // the next two tiles load into the other half of the ring meanwhile
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) split3(vf[i][0], vf[i][1], vs[i][0], vs[i][1], vs[i][2]);
+        load_v(p + 1);                                  // vf is free again
+#pragma unroll
+        for (int g = 0; g < (TN + 1) / 2; ++g) {        // tiles 2g, 2g+1 (the last group has one tile + a dummy)
+            const int s = p * 8 + 2 * g;                // ring position: 8 slots per pair (7 tiles + 1 dummy)
+            {
+                const int sn = s + 2, pn = sn / 8, jn = sn % 8;
+                if (jn < TN) load_u(sn % RING, pn * TN + jn);
+                if (jn + 1 < TN) load_u((sn + 1) % RING, pn * TN + jn + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int j = 2 * g + jj;
+                        if (j < TN)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, ub[(s + jj) % RING][UT[t]]),
+                                __builtin_bit_cast(bf16x8, vs[i][VT[t]]), acc[j][i], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int pb = pt * m_point + kq * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cg = wn * TN + j;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 a = acc[j][i];
+            __builtin_amdgcn_raw_buffer_store_b128(
+                i32x4{__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])},
+                mr, cg < CG && v_row[i] != OOB ? v_row[i] + pb + cg * v_chunk : OOB, 0, 0);
+        }
+    }
+}
+
+// 1: bf16x3 GEMM (needs the split copy of U^T behind the fp32 one, see decnet_conv3d_wino_pack_weight)
+static int gemm_bf16x3() {
+    static const int k = [] { const char *e = getenv("DECNET_WINO_GEMM"); return e && !strcmp(e, "bf16x3") ? 1 : 0; }();
+    return k;
+}
+
 template <int WM>
 int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                 hipStream_t stream) {
@@ -512,12 +680,17 @@ int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co
 int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                   hipStream_t s) {
     static const int tile_env = [] { const char *e = getenv("DECNET_WINO_TILE"); return e ? atoi(e) : 0; }();
+    if (gemm_bf16x3() && Ci == 216) {
+        static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
+        const int *Ub = reinterpret_cast<const int *>(U + (size_t)np * pad16(Ci) * W_BN);   // split copy behind U^T
+        hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(nt, 96), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
+                           Co, np, swz);
+        return decnet_launch_status();
+    }
     return tile_env == 192 ? launch_gemm<4>(V, U, M, nt, Ci, Co, np, s)
          : tile_env == 48 ? launch_gemm<1>(V, U, M, nt, Ci, Co, np, s)
                           : launch_gemm<2>(V, U, M, nt, Ci, Co, np, s);
 }
-
-__host__ __device__ constexpr int pad16(int c) { return (c + 15) & ~15; }
 
 // tiles per chunk: V + M of one chunk <= DECNET_WINO_CHUNK_MB (1 GiB); equal chunks
 int chunk_tiles(int T, int C, int np) {
@@ -571,7 +744,11 @@ extern "C" {
 /* variant: 0 = F(2,3)^3 (64 transform points), 1 = F(2,3) on D x F(4,3) on H, W (144 points) */
 size_t decnet_conv3d_wino_weight_floats(int Ci, int variant) {
     const int np = variant_points(variant);
-    return np < 0 || Ci < 1 ? 0 : (size_t)np * pad16(Ci) * W_BN;
+    if (np < 0 || Ci < 1) return 0;
+    const size_t f32 = (size_t)np * pad16(Ci) * W_BN;
+    // + the bf16 hi/mid/lo split of U^T for the bf16x3 GEMM: 3 terms x 2 bytes per (padded to pairs of chunks) k
+    const size_t split = gemm_bf16x3() ? (size_t)np * ((pad16(Ci) / 16 + 1) / 2) * 3 * W_BN * 16 : 0;
+    return f32 + split;
 }
 
 int decnet_conv3d_wino_pack_weight(const float *w, float *u, int Co, int Ci, int variant, void *stream) {
@@ -585,6 +762,12 @@ int decnet_conv3d_wino_pack_weight(const float *w, float *u, int Co, int Ci, int
     else
         hipLaunchKernelGGL((wino_weight_transform<4, 6, 6>), dim3(ceil_div(n, 128)), dim3(128), 0,
                            (hipStream_t)stream, w, u, Co, Ci);
+    int rc = decnet_launch_status();
+    if (rc || !gemm_bf16x3()) return rc;
+    const int np = variant_points(variant), KC = pad16(Ci) / 16;
+    const int nthr = np * ((KC + 1) / 2) * W_BN * 4;
+    hipLaunchKernelGGL(wino_split_weights, dim3(ceil_div(nthr, 256)), dim3(256), 0, (hipStream_t)stream, u,
+                       reinterpret_cast<int *>(u + (size_t)np * pad16(Ci) * W_BN), np, KC, Ci);
     return decnet_launch_status();
 }
 
