@@ -377,7 +377,11 @@ def main():
                                  "traffic": traffic.get("spamat_fused_stage3", {}).get("total_bytes"),
                                  "kernel": "spamat fused fwd, stage 3",
                                  "mask_density": args.mask_density, "ms": s3_ms,
-                                 "bytes_per_launch": s3_bytes},
+                                 "bytes_per_launch": s3_bytes,
+                                 "note": "at mask density 1.0 this pass is FP32-issue bound, not HBM bound: 806.7 M "
+                                         "candidates x ~12 VALU-op equivalents + 8 MFMA MACs each cap it near 0.2 "
+                                         "of 8 TB/s (DESIGN.md section 4); the HBM-shaped regime is the sparse one "
+                                         "in roofline_costvol_sparse"},
         }
         if sparse:
             out["roofline_costvol_sparse"] = sparse
