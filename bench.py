@@ -32,13 +32,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 matrix peak (v_mfma_f32_*_f32)
 
-PAD_H, PAD_W, MAX_DISP = 540, 972, 216
-STAGES = [  # (C, H, W, D) for stage 0..3 of the shipped 4-stage / scale-3 network
-    (216, PAD_H // 27, PAD_W // 27, MAX_DISP // 27),
-    (72, PAD_H // 9, PAD_W // 9, MAX_DISP // 9),
-    (24, PAD_H // 3, PAD_W // 3, MAX_DISP // 3),
-    (8, PAD_H, PAD_W, MAX_DISP),
-]
+# BASELINE.json configs that fit one process per GPU: (name, padded H, padded W, rounded max_disp, pairs per GPU)
+CONFIGS = {
+    2: ("config 2: synthetic 960x540 (padded 972x540), max_disp 192->216", 540, 972, 216, 8),
+    3: ("config 3: KITTI 1242x375 (padded 1242x378), max_disp 192->216, batch 32 over 8 GPUs", 378, 1242, 216, 4),
+    4: ("config 4: Middlebury half-res 1500x1000 (padded 1512x1026), max_disp 256->270", 1026, 1512, 270, 1),
+}
+CONFIG_NAME, PAD_H, PAD_W, MAX_DISP, DEFAULT_B = CONFIGS[2]
+
+
+def stage_shapes(h, w, md):
+    """(C, H, W, D) for stage 0..3 of the shipped 4-stage / scale-3 network."""
+    return [(216, h // 27, w // 27, md // 27), (72, h // 9, w // 9, md // 9), (24, h // 3, w // 3, md // 3),
+            (8, h, w, md)]
+
+
+STAGES = stage_shapes(PAD_H, PAD_W, MAX_DISP)
+
+
+def set_config(n):
+    global CONFIG_NAME, PAD_H, PAD_W, MAX_DISP, DEFAULT_B, STAGES
+    CONFIG_NAME, PAD_H, PAD_W, MAX_DISP, DEFAULT_B = CONFIGS[n]
+    STAGES = stage_shapes(PAD_H, PAD_W, MAX_DISP)
 
 
 def make_inputs(B, dev, density, seed):
@@ -237,7 +252,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=8)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json config (2 = the metric's; 3, 4: the other single-GPU-shard shapes)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0, help="default: the config's (8 / 4 / 1)")
     ap.add_argument("--mask-density", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-density-sweep", action="store_true",
@@ -262,7 +279,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
-    B = args.pairs_per_gpu
+    set_config(args.config)
+    B = args.pairs_per_gpu or DEFAULT_B
     hp = HotPath(B, dev, args.mask_density, world)
 
     def barrier():
@@ -357,13 +375,14 @@ def main():
                                   "kernel": "spamat sparse-row kernel (+ marker launch), fused fwd, stage 3",
                                   "mask_density": 0.1, "ms": t}
         out = {
-            "metric": "stereo pairs/sec at 960x540x192disp (hot path: stage-0 dense + SpaMat/SpaVar stages 1-3)",
+            "metric": ("stereo pairs/sec at 960x540x192disp" if args.config == 2 else
+                       "stereo pairs/sec, BASELINE config %d shapes" % args.config) +
+                      " (hot path: stage-0 dense + SpaMat/SpaVar stages 1-3)",
             "value": pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: batch=%d synthetic 960x540 pairs per GPU (padded "
-                                   "972x540), max_disp 192->216, feature maps of the 4-stage/scale-3 net, "
-                                   "random-init CostRegNetNoDown(216)" % B,
+            "config": {"workload": "BASELINE %s: batch=%d synthetic pairs per GPU, feature maps of the "
+                                   "4-stage/scale-3 net, random-init CostRegNetNoDown(216)" % (CONFIG_NAME, B),
                        "pairs_per_gpu": B, "mask_density": args.mask_density,
                        "parallelism": "dp%d (pairs sharded, all_gather of disparity maps)" % world},
             "roofline": {"bound": "mfma", "achieved": kern_flop / conv_ms / 1e9, "peak": MFMA_F32_PEAK_TF,
