@@ -730,7 +730,12 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const int dchunk = D >= 8 ? 2 : 1;
+    // disparities per workgroup: the row staging (3 x C x W floats, three dependent load batches) is the
+    // expensive part, so a workgroup keeps its rows for as many d as still leaves >= ~1 workgroup per CU
+    static const int dc_env = [] { const char *e = getenv("DECNET_COSTVOL_DCHUNK"); return e ? atoi(e) : 0; }();
+    int dchunk = 1;
+    while (dchunk < D && (long)B * H * ceil_div(D, 2 * dchunk) >= 160) dchunk *= 2;
+    if (dc_env > 0) dchunk = dc_env;
     hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H), (unsigned)ceil_div(D, dchunk)),
                        dim3(512), lds, (hipStream_t)stream, left, right, cost, C, H, W, D, dchunk);
     return decnet_launch_status();
