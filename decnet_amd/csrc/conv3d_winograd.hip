@@ -10,7 +10,7 @@
 // fp32 throughout.  Two tile shapes (the `variant` argument of the entry points):
 //   0  F(2,3) on D, H and W: 4x4x4 input tile -> 2x2x2 outputs, 64 transform points, 8 multiplies
 //      per output (27 direct).  Constants 0, +-1, +-1/2: as accurate as the direct convolution
-//      (tools/conv_numerics.py, against float64: 1.8e-6 relative on the regularised volume, the
+//      (tests/conv_numerics.py, against float64: 1.8e-6 relative on the regularised volume, the
 //      direct kernel 2.9e-6, torch CPU 1.5e-6).
 //   1  F(2,3) on D, F(4,3) on H and W: 4x6x6 tile -> 2x4x4 outputs, 144 points, 4.5 multiplies
 //      per output; constants up to 8 and 1/24: 6.0e-6 relative on the volume, 2.3e-5 px mean on

@@ -1,12 +1,12 @@
-"""tools/conv_numerics.py -- how far each Conv3d algorithm of the HIP stage-0 path is from the exact
-result, next to the fp32 CPU oracle's own rounding error.  (Uses oracle/ as the checker: a tool, not
-product code.)
+"""tests/conv_numerics.py -- how far each Conv3d algorithm of the HIP stage-0 path is from the exact
+result, next to the fp32 CPU oracle's own rounding error.  A measurement script, not a pytest module; it
+lives under tests/ because it uses oracle/ as the checker.
 
 Ground truth = the oracle (oracle/stage0.py) evaluated in float64.  For each `sharpness` s the last
 BatchNorm's gamma/beta are multiplied by s, which scales the logits of the soft-argmax the way a
 trained, confident network's are (random-init logits are almost flat).
 
-    python tools/conv_numerics.py [--shape 8,20,36] [--c 216] [--sharp 1,10,100]
+    python tests/conv_numerics.py [--shape 8,20,36] [--c 216] [--sharp 1,10,100]
 """
 import argparse
 import os
