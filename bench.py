@@ -142,7 +142,7 @@ class HotPath:
         return pred0, disp
 
 
-def time_kernel(fn, iters, warm=3):
+def time_kernel(fn, iters, warm=10):
     for _ in range(warm):
         fn()
     beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -342,9 +342,9 @@ def main():
                 V, Mw = wsp[:npts * nt * cp], wsp[npts * nt * cp:]
                 layer_ms = time_kernel(lambda: L.decnet_conv3d_wino_bn_act(
                     cv.data_ptr(), p0["u"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr(), None,
-                    a.data_ptr(), wsp.data_ptr(), B, D0, H0, W0, C0, C0, 1, var, st), 10)
+                    a.data_ptr(), wsp.data_ptr(), B, D0, H0, W0, C0, C0, 1, var, st), 30)
                 conv_ms = time_kernel(lambda: L.decnet_conv3d_wino_gemm(
-                    V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, var, st), 10)
+                    V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, var, st), 60)
                 kern_flop = 2.0 * npts * nt * C0 * C0
                 kern_name = "wino_gemm (%d x [%d x %d] x [%d x %d], %s Conv3d 216->216)" % (
                     npts, nt, C0, C0, C0, "Winograd F(2,3)^3" if var == 0 else "Winograd F(2,3)xF(4,3)^2")
