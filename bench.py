@@ -9,8 +9,10 @@ max_disp 192 -> 216 as the reference rounds it, demo.py:153):
               -> soft-argmax                                    [8,216,20,36], D=8
     stage 1-3 fused SpaMat+SpaVar (masked correlation -> softmax expectation + variance)
               [8,72,60,108] D=24 / [8,24,180,324] D=72 / [8,8,540,972] D=216
+              (independent of stage 0's result: enqueued on a second HIP stream beside it)
     N>1       one RCCL all_gather of the per-rank disparity maps (the reference's
-              DataParallel gather, eval.py:146) -- pairs are sharded, weak scaling.
+              DataParallel gather, eval.py:146) -- pairs are sharded, weak scaling; the gather
+              of step k overlaps step k+1.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -104,6 +106,7 @@ class HotPath:
         # the receive buffers are double buffered
         self.outs3 = [self.outs[2], tuple(torch.empty_like(t) for t in self.outs[2])]
         self.gbuf, self.pending, self.k = [None, None], [None, None], 0
+        self.side = None
         self.ev = None
 
     def drain(self):
@@ -114,24 +117,48 @@ class HotPath:
                 self.pending[i] = None
 
     def step(self, events=None):
+        """One pass.  SpaMat/SpaVar of stages 1-3 depend on the features and masks only, not on stage 0's
+        result, so they run on a second HIP stream beside the stage-0 convolution stack (they fill its
+        kernel tails: ~3 %).  With `events` (the untimed breakdown steps) everything runs in order on one
+        stream so that the per-stage times are clean."""
         d = self.decnet
-        L, R = self.feats[0]
-        if events is not None:
-            events["s0_beg"].record()
-        pred0 = self.stage0(L, R, STAGES[0][3])
-        if events is not None:
-            events["s0_end"].record()
-        for s in (1, 2, 3):
-            (L, R), (rm, tm) = self.feats[s], self.masks[s]
-            if events is not None and s == 3:
-                events["s3_beg"].record()
-            par = self.k & 1 if self.world > 1 else 0
-            if s == 3 and self.pending[par] is not None:     # the gather that read this buffer set two steps ago
-                self.pending[par].wait()
-                self.pending[par] = None
-            d.spamatvar_forward(L, R, rm, tm, STAGES[s][3], out=self.outs3[par] if s == 3 else self.outs[s - 1])
-            if events is not None and s == 3:
-                events["s3_end"].record()
+        cur = torch.cuda.current_stream()
+        overlap = events is None
+        if overlap:
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            self.side.wait_stream(cur)
+
+        def stage0():
+            L, R = self.feats[0]
+            if events is not None:
+                events["s0_beg"].record()
+            p = self.stage0(L, R, STAGES[0][3])
+            if events is not None:
+                events["s0_end"].record()
+            return p
+
+        def sparse_stages():
+            for s in (3, 2, 1):
+                (L, R), (rm, tm) = self.feats[s], self.masks[s]
+                if events is not None and s == 3:
+                    events["s3_beg"].record()
+                par = self.k & 1 if self.world > 1 else 0
+                if s == 3 and self.pending[par] is not None:  # the gather that read this buffer set two steps ago
+                    self.pending[par].wait()
+                    self.pending[par] = None
+                d.spamatvar_forward(L, R, rm, tm, STAGES[s][3], out=self.outs3[par] if s == 3 else self.outs[s - 1])
+                if events is not None and s == 3:
+                    events["s3_end"].record()
+
+        if overlap:
+            with torch.cuda.stream(self.side):
+                sparse_stages()
+            pred0 = stage0()
+            cur.wait_stream(self.side)
+        else:
+            pred0 = stage0()
+            sparse_stages()
         disp = self.outs3[self.k & 1 if self.world > 1 else 0][0]
         if self.world > 1:       # one RCCL all-gather of the per-rank disparity maps, not waited for here
             par = self.k & 1
