@@ -40,6 +40,12 @@ SIGNATURES = {
     "decnet_conv2d_cat_bn_act": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P],
     "decnet_warp_disparity": [_P, _P, _P] + [_I] * 4 + [_P],
     "decnet_dynamic_upsample3": [_P, _P, _P] + [_I] * 3 + [_P],
+    "decnet_tapconv_chunk_floats": [_I] * 4,
+    "decnet_tapconv_to_chunks": [_P, _P] + [_I] * 4 + [_P],
+    "decnet_tapconv_weight_floats": [_I, _I],
+    "decnet_tapconv_pack_weight": [_P, _P] + [_I] * 4 + [_P],
+    "decnet_tap_gemm": [_P, _P, _P] + [_I] * 4 + [_P],
+    "decnet_tapconv_gather": [_P, _P, _P, _P] + [_I] * 5 + [_P, _P, _P, _I, _P],
     "decnet_conv3d_cout1_workspace_floats": [_I] * 4,
     "decnet_conv3d_cout1_softargmax_ws": [_P, _P, _F, _F, _P, _P, _P] + [_I] * 5 + [_P],
     "decnet_disparity_regression": [_P] * 3 + [_I] * 4 + [_P],

@@ -350,14 +350,16 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, int voff)
 template <int NFULL, int TAIL, int TM>
 __device__ __forceinline__ void wino_gemm_wave(const float *__restrict__ Vb, const float *__restrict__ Ub,
                                                float *__restrict__ Mb, int nt, int Ci, int Co, int xg,
-                                               int np, int xi0, int m0, int wn) {
+                                               int np, int xi0, int m0, int wn, int v_shared) {
     constexpr int TN = 7, OOB = 0x7fffffff;
     const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
     if (m0 >= nt) return;                               // no barriers: idle waves of the M tail just leave
     const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;
     const int v_chunk = nt * 64, u_chunk = W_BN * 64;                 // bytes per 16-channel chunk
-    const int v_point = KC * v_chunk, u_point = KC * u_chunk, m_point = CG * v_chunk;
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * v_point, 0x00020000);
+    // v_shared: every "point" multiplies the SAME V (decnet_tap_gemm: the taps of a dilated convolution)
+    const int v_point = v_shared ? 0 : KC * v_chunk, u_point = KC * u_chunk, m_point = CG * v_chunk;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)Vb, 0, v_shared ? KC * v_chunk : np * v_point, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ub, 0, np * u_point, 0x00020000);
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * m_point, 0x00020000);
     int v_row[TM], u_row[TN];                           // byte offset of this lane's row inside a chunk
@@ -486,13 +488,13 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
     // L2 then holds U of one point group at a time instead of every XCD streaming all of U.
     const int mblocks = gridDim.x, ngroups = gridDim.y;
     int pg = blockIdx.y, mb = blockIdx.x;
-    if (swz) {
+    if (swz & 1) {
         const int id = blockIdx.y * mblocks + blockIdx.x, per8 = 8 * mblocks;
         const int r = id / per8, q = id - r * per8;
         if (8 * (r + 1) <= ngroups) { pg = 8 * r + (q & 7); mb = q >> 3; }     // tail (< 8 groups) unswizzled
     }
     const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-    wino_gemm_wave<NFULL, TAIL, 3>(Vb, Ub, Mb, nt, Ci, Co, xg, np, pg * xg, (mb * WM + wm) * 48, wn);
+    wino_gemm_wave<NFULL, TAIL, 3>(Vb, Ub, Mb, nt, Ci, Co, xg, np, pg * xg, (mb * WM + wm) * 48, wn, swz & 2);
 }
 
 // ------------------------------ the same GEMM on the bf16 matrix cores, fp32 accurate ------------
@@ -664,11 +666,12 @@ static int gemm_bf16x3() {
 
 template <int WM>
 int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
-                hipStream_t stream) {
+                hipStream_t stream, int v_shared = 0) {
     static const int xg_env = [] { const char *e = getenv("DECNET_WINO_XG"); return e ? atoi(e) : 0; }();
     int xg = 1;                                         // points per workgroup (experiments: 1 is best)
     if (xg_env > 0 && np % xg_env == 0) xg = xg_env;
-    static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
+    static const int swz_env = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
+    const int swz = (swz_env ? 1 : 0) | (v_shared ? 2 : 0);
     const dim3 grid(ceil_div(nt, WM * 48), np / xg), block(WM * 128);
     if (Ci == 216)
         hipLaunchKernelGGL((wino_gemm<WM, 13, 2>), grid, block, 0, stream, V, U, M, nt, Ci, Co, xg, np, swz);
@@ -782,6 +785,18 @@ int decnet_conv3d_wino_gemm(const float *V, const float *u, float *M, int nt, in
     if (Ci % 4 != 0 || Co > W_BN || (double)nt * pad16(Ci > Co ? Ci : Co) * 4 * np >= 2147483647.0)
         return DECNET_ERR_UNSUPPORTED;
     return gemm_dispatch(V, u, M, nt, Ci, Co, np, (hipStream_t)stream);
+}
+
+/* M[t] = V * U[t] for t < ntaps: ONE V [ceil(Ci/16)][P][16] against ntaps weight matrices
+ * u [ntaps][ceil(Ci/16)][224][16] -> M [ntaps][ceil(Co/16)][P][16] (decnet_tapconv_*: dilated convolutions as a
+ * per-tap product + gather). */
+int decnet_tap_gemm(const float *V, const float *u, float *M, int P, int Ci, int Co, int ntaps, void *stream) {
+    if (!V || !u || !M) return DECNET_ERR_NULL_POINTER;
+    if (P < 1 || Ci < 1 || Co < 1 || ntaps < 1) return DECNET_ERR_BAD_SHAPE;
+    if (Ci % 4 != 0 || Co > W_BN || (double)P * pad16(Ci > Co ? Ci : Co) * 4 * ntaps >= 2147483647.0 ||
+        (double)ntaps * pad16(Ci) * W_BN * 4 >= 2147483647.0)
+        return DECNET_ERR_UNSUPPORTED;
+    return launch_gemm<2>(V, u, M, P, Ci, Co, ntaps, (hipStream_t)stream, 1);
 }
 
 size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co, int variant) {

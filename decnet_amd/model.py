@@ -222,7 +222,81 @@ class ASPP(nn.Module):
         for i, r in enumerate(rates):
             self.stages.add_module("c%d" % (i + 1), Unit(cin, cout, 3, pad=r, dil=r))
 
+    # ---- fused path (csrc/tapconv.hip): one V, one batched per-tap GEMM, one gather for all branches ----
+    def _hip_ok(self, x):
+        if (self.training or not x.is_cuda or x.dtype != torch.float32 or torch.is_grad_enabled() or
+                os.environ.get("DECNET_CONV2D", "hip") != "hip"):
+            return False
+        units = list(self.stages.children())
+        c0 = units[0].conv
+        if len(units) > 4 or c0.in_channels % 4 or c0.out_channels > 224 or x.shape[-1] * x.shape[-2] > 16384:
+            return False
+        for u in units:
+            c = u.conv
+            k = c.kernel_size[0]
+            if (not isinstance(c, nn.Conv2d) or u.bn is None or not u.relu or c.kernel_size not in ((1, 1), (3, 3)) or
+                    c.stride != (1, 1) or c.dilation[0] != c.dilation[1] or c.groups != 1 or
+                    c.padding != (c.dilation[0] * (k // 2),) * 2 or c.out_channels != c0.out_channels or
+                    c.in_channels != c0.in_channels):
+                return False
+        return True
+
+    def _packed(self):
+        from . import _lib
+        units = list(self.stages.children())
+        ts = [t for u in units for t in (u.conv.weight, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var)]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_pk_key", None) != key:
+            L = _lib.lib()
+            dev = units[0].conv.weight.device
+            ci, co = units[0].conv.in_channels, units[0].conv.out_channels
+            ks = [u.conv.kernel_size[0] for u in units]
+            tap0 = [sum(k * k for k in ks[:i]) for i in range(len(ks))]
+            ntaps = sum(k * k for k in ks)
+            with torch.no_grad(), torch.cuda.device(dev):
+                st = torch.cuda.current_stream(dev).cuda_stream
+                u_all = torch.empty(L.decnet_tapconv_weight_floats(ci, ntaps), dtype=torch.float32, device=dev)
+                scale, shift = [], []
+                for u, k, t0 in zip(units, ks, tap0):
+                    w = u.conv.weight.detach().float().contiguous()
+                    _lib.check(L.decnet_tapconv_pack_weight(w.data_ptr(), u_all.data_ptr(), co, ci, k, t0, st),
+                               "decnet_tapconv_pack_weight")
+                    sc = u.bn.weight.float() / torch.sqrt(u.bn.running_var.float() + u.bn.eps)
+                    scale.append(sc)
+                    shift.append(u.bn.bias.float() - u.bn.running_mean.float() * sc)
+                torch.cuda.current_stream(dev).synchronize()          # w temporaries may go now
+            self._pk = dict(u=u_all, scale=torch.cat(scale).contiguous(), shift=torch.cat(shift).contiguous(),
+                            ks=ks, tap0=tap0, ntaps=ntaps, dil=[u.conv.dilation[0] for u in units])
+            self._pk_key = key
+        return self._pk
+
+    def _forward_hip(self, x):
+        import ctypes
+        from . import _lib
+        from .ops import _stream
+        pk = self._packed()
+        L = _lib.lib()
+        x = x.contiguous()
+        B, Ci, H, W = x.shape
+        Co, nb = list(self.stages.children())[0].conv.out_channels, len(pk["ks"])
+        P = B * H * W
+        V = torch.empty(L.decnet_tapconv_chunk_floats(B, Ci, H, W), dtype=torch.float32, device=x.device)
+        T = torch.empty(pk["ntaps"] * ((Co + 15) // 16) * 16 * P, dtype=torch.float32, device=x.device)
+        y = torch.empty((B, nb * Co, H, W), dtype=torch.float32, device=x.device)
+        arr = lambda v: (ctypes.c_int * len(v))(*v)
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            _lib.check(L.decnet_tapconv_to_chunks(x.data_ptr(), V.data_ptr(), B, Ci, H, W, st), "decnet_tapconv_to_chunks")
+            _lib.check(L.decnet_tap_gemm(V.data_ptr(), pk["u"].data_ptr(), T.data_ptr(), P, Ci, Co, pk["ntaps"], st),
+                       "decnet_tap_gemm")
+            _lib.check(L.decnet_tapconv_gather(T.data_ptr(), pk["scale"].data_ptr(), pk["shift"].data_ptr(),
+                                               y.data_ptr(), B, Co, H, W, nb, arr(pk["tap0"]), arr(pk["ks"]),
+                                               arr(pk["dil"]), 1, st), "decnet_tapconv_gather")
+        return y
+
     def forward(self, x):
+        if self._hip_ok(x):
+            return self._forward_hip(x)
         return torch.cat([s(x) for s in self.stages.children()], 1)
 
 

@@ -115,6 +115,27 @@ def test_dynamic_upsampling_tail_kernel(dev):
     assert float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("c,rates,shape", [(216, [4, 8, 12], (2, 20, 36)), (24, [1, 2, 5], (1, 7, 9))])
+def test_aspp_tap_gemm_path(dev, c, rates, shape):
+    """ASPP (1x1 + three dilated 3x3 branches, concatenated) through the per-tap GEMM + gather path
+    == the four torch convolutions on CPU."""
+    from decnet_amd.model import ASPP
+    torch.manual_seed(c)
+    m = ASPP(c, c, rates).eval()
+    for u in m.stages.children():
+        u.bn.weight.data.uniform_(0.5, 1.5); u.bn.bias.data.normal_(0, 0.2)
+        u.bn.running_mean.data.normal_(0, 0.2); u.bn.running_var.data.uniform_(0.5, 1.5)
+    B, H, W = shape
+    x = torch.randn(B, c, H, W, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = m(x)
+        md = m.to(dev)
+        assert md._hip_ok(x.to(dev))
+        got = md(x.to(dev)).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_unit_falls_back_when_not_covered(dev):
     u = _unit(24, 24, 3).to(dev)                            # 24 -> 24 channels, no dilation: MIOpen path
     x = torch.randn(1, 24, 300, 300, device=dev)
