@@ -467,8 +467,16 @@ class SparseDenseNetRefinementMask(nn.Module):
                 is_check=False, is_eval=False):
         if self.training:
             raise NotImplementedError("inference only: call .eval() (SURVEY.md S11)")
-        lf = self.feature_extractor(left)
-        rf = self.feature_extractor(right)
+        if left.is_cuda and left.shape == right.shape and os.environ.get("DECNET_FEAT_BATCH", "1") == "1":
+            # both views in one pass (per-sample ops, eval BN: same result; the 1/9 and 1/27 layers
+            # are too small at B pairs to fill 256 CUs)
+            f2 = self.feature_extractor(torch.cat([left, right]))
+            nb = left.shape[0]
+            lf = {k: v[:nb] for k, v in f2.items()}
+            rf = {k: v[nb:] for k, v in f2.items()}
+        else:
+            lf = self.feature_extractor(left)
+            rf = self.feature_extractor(right)
         pred = None
         for stage in range(self.num_stage):
             L, R = lf["stage%d" % stage], rf["stage%d" % stage]
