@@ -660,16 +660,6 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
         }
         S >>= 1;
     }
-    // zero fill of the masked-off left pixels (functions/SpaMat.py:25-27 semantics)
-    for (int p = tid; p < W; p += SP_THREADS) {
-        if (RKL[p + 1] == RKL[p]) {
-            const size_t pix = rowpix + p;
-            if (MODE != MODE_VAR) out[pix] = 0.f;
-            if (MODE != MODE_MAT) var_out[pix] = 0.f;
-            sum_sim[pix] = 0.f;
-            max_cost[pix] = 0.f;
-        }
-    }
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {
         RF[c * SP_FP + tid] = rf[c];                    // slots >= nR hold zeros
@@ -713,11 +703,51 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
             const float mu_in = (MODE == MODE_VAR && act) ? disparity[pix] : 0.f;
             softmax_passes<NTC, MODE, true>(acc, ntile, D, 0, smem, 0, offXR + 16 * t0 + 4 * q, xl, mu_in, mx,
                                             Ssum, mu, var);
+            // results go to rows 0..3 of this chunk's own LF slots (their features were consumed
+            // into bcur above and no other wave reads them); the row is written once at the end
             if (act && q == 0) {
-                if (MODE != MODE_VAR) out[pix] = mu;
-                if (MODE != MODE_MAT) var_out[pix] = var;
-                sum_sim[pix] = Ssum;
-                max_cost[pix] = mx;
+                if (MODE != MODE_VAR) LF[el] = mu;
+                if (MODE != MODE_MAT) LF[SP_FP + el] = var;
+                LF[2 * SP_FP + el] = Ssum;
+                LF[3 * SP_FP + el] = mx;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 4. one coalesced sweep over the row: results of the active left pixels, zeros elsewhere
+    // (functions/SpaMat.py:25-27 semantics).  Every output line is written exactly once: scattered
+    // result stores behind a zero fill cost 1.65x the algorithmic write traffic (WRITE_SIZE).
+    {
+        int slot = baseL + il - cl;                     // exclusive count at p4
+        const bool alo = ((W & 3) == 0) && ((((uintptr_t)out) | ((uintptr_t)var_out) | ((uintptr_t)sum_sim) |
+                                             ((uintptr_t)max_cost)) & 15) == 0;
+#pragma unroll
+        for (int u = 0; u < PPT; u += 4) {
+            if (p4 + u >= W) break;
+            float r[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool on = fl & (1 << (u + k));
+#pragma unroll
+                for (int o = 0; o < 4; ++o) r[o][k] = on ? LF[o * SP_FP + slot] : 0.f;
+                slot += on;
+            }
+            const size_t pix = rowpix + p4 + u;
+            if (alo) {
+                if (MODE != MODE_VAR) *reinterpret_cast<float4 *>(out + pix) = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
+                if (MODE != MODE_MAT) *reinterpret_cast<float4 *>(var_out + pix) = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+                *reinterpret_cast<float4 *>(sum_sim + pix) = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+                *reinterpret_cast<float4 *>(max_cost + pix) = make_float4(r[3][0], r[3][1], r[3][2], r[3][3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (p4 + u + k < W) {
+                        if (MODE != MODE_VAR) out[pix + k] = r[0][k];
+                        if (MODE != MODE_MAT) var_out[pix + k] = r[1][k];
+                        sum_sim[pix + k] = r[2][k];
+                        max_cost[pix + k] = r[3][k];
+                    }
+                }
             }
         }
     }
