@@ -347,7 +347,8 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
     // words: XR [LP] | XL [LP] | RK, RKL [(NPX+4) x u16] | WT [16] | NM, OUT, GS, MU [LP] | RF, LF [CQ][FP]
     constexpr int offXR = 0, offXL = SB_LP, offRK = 2 * SB_LP, offRKL = offRK + RKW, offWT = offRKL + RKW,
                   offNM = offWT + 16, offOUT = offNM + SB_LP, offGS = offOUT + SB_LP, offMU = offGS + SB_LP,
-                  offRF = offMU + SB_LP, offLF = offRF + CQ * SB_FP;
+                  offRF = offMU + SB_LP, offLF = offRF + CQ * SB_FP, offSC = offLF + CQ * SB_FP,
+                  SCW = (CQ + 1) * 16;                   // per wave: [CQ gradient channels + grad_disparity][16 slots]
     int *XR = reinterpret_cast<int *>(smem) + offXR;
     int *XL = reinterpret_cast<int *>(smem) + offXL;
     unsigned short *RK = reinterpret_cast<unsigned short *>(smem + offRK);
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
     float *RF = smem + offRF, *LF = smem + offLF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *SC = smem + offSC + wave * SCW;
     const int row = blockIdx.x, b = row / H, y = row - b * H;
     const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
     const float *lrow = ref + ((size_t)b * C * H + y) * W;
@@ -428,33 +430,6 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
             gs = grad_out[rowpix + xl_own] / sum_sim[rowpix + xl_own];
             if (VAR) mu = disparity[rowpix + xl_own];
         }
-        // 16-byte stores for the quads without an active pixel (most of them), scalars for the rest
-        const bool v4 = (W & 3) == 0 && (((uintptr_t)glrow | (uintptr_t)grrow | (uintptr_t)(plane * 4)) & 15) == 0;
-        auto zero_fill = [&](float *rowp, int bits, size_t cstride, int nc) {
-#pragma unroll
-            for (int u = 0; u < PPT; u += 4) {
-                if (p0 + u >= W) continue;
-                const int qb = (bits >> u) & 15;
-                if (qb == 15) continue;
-                for (int c = 0; c < nc; ++c) {
-                    float *o = rowp + (size_t)c * cstride + p0 + u;
-                    if (qb == 0 && v4) {
-                        *reinterpret_cast<float4 *>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (p0 + u + k < W && !((qb >> k) & 1)) o[k] = 0.f;
-                    }
-                }
-            }
-        };
-        zero_fill(glrow, fl, plane, C);
-        zero_fill(grrow, fr, plane, C);
-        if (VAR) {
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-                if (p0 + k < W && !((fl >> k) & 1)) grad_disp[rowpix + p0 + k] = 0.f;
-        }
 #pragma unroll
         for (int c = 0; c < CQ; ++c) {
             RF[c * SB_FP + tid] = rf[c];                // slots >= nR / nL hold zeros
@@ -476,6 +451,13 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
         const int *XT = side == 0 ? XR : XL;           // other positions
         const float *FO = side == 0 ? LF : RF, *FT = side == 0 ? RF : LF;
         float *grow = side == 0 ? glrow : grrow;
+        if (n_own == 0) {                               // no chunk writes anything: the row is all zeros
+            for (int pp = tid; pp < W; pp += SB_THREADS) {
+                for (int c = 0; c < C; ++c) grow[(size_t)c * plane + pp] = 0.f;
+                if (VAR && side == 0) grad_disp[rowpix + pp] = 0.f;
+            }
+            continue;
+        }
         for (int e = 16 * wave; e < n_own; e += 16 * SB_NWAVE) {
             const bool act = e + j < n_own;
             const int xo = XO[act ? e + j : n_own - 1];
@@ -553,23 +535,40 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
                     }
                 }
             }
-            // gacc[cb][r]: channel 16*cb + (lane & 15), own slot e + 4q + r
+            // gacc[cb][r]: channel 16*cb + (lane & 15), own slot e + 4q + r.  The chunk goes through
+            // this wave's scratch and out as whole lines: the wave writes every pixel from its first
+            // active one up to the next chunk's first (chunk 0 from pixel 0, the last one to W) --
+            // gradients at the active pixels, zeros between them -- so every line of the row is
+            // written once (a zero fill + scattered stores cost 1.6x the gradient bytes, WRITE_SIZE).
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const int c = 16 * cb + j;
-                if (c < C) {
+                if (c < CQ) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int oi = e + 4 * q + r;
-                        if (oi < n_own) grow[(size_t)c * plane + XO[oi]] = gacc[cb][r] * (side == 0 ? GS[oi] : 1.f);
+                        SC[c * 16 + 4 * q + r] = gacc[cb][r] * (side == 0 ? GS[oi] : 1.f);   // GS: padded to n + 16
                     }
                 }
             }
             if (VAR && side == 0) {
                 gdis += __shfl_xor(gdis, 16);
                 gdis += __shfl_xor(gdis, 32);
-                if (act && q == 0) grad_disp[rowpix + xo] = -2.f * GS[e + j] * gdis;
+                if (q == 0) SC[CQ * 16 + j] = -2.f * GS[e + j] * gdis;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned short *RO = side == 0 ? RKL : RK;       // exclusive own-side counts
+            const int p_beg = e == 0 ? 0 : x_lo, p_end = e + 16 >= n_own ? W : XO[e + 16];
+            for (int pp = p_beg + lane; pp < p_end; pp += 64) {
+                const int r0 = RO[pp], sl = r0 - e;
+                const bool on = RO[pp + 1] != r0;
+                for (int c = 0; c < C; ++c) grow[(size_t)c * plane + pp] = on ? SC[c * 16 + sl] : 0.f;
+                if (VAR && side == 0) grad_disp[rowpix + pp] = on ? SC[CQ * 16 + sl] : 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -589,7 +588,7 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
             marker = 1;
             const int ppt = W <= 1024 ? 4 : 8;
             const size_t slds = 4 * (size_t)(2 * SB_LP + 2 * (SB_THREADS * ppt / 2 + 2) + 16 + 4 * SB_LP +
-                                             2 * 4 * KQ * SB_FP);
+                                             2 * 4 * KQ * SB_FP + SB_NWAVE * (4 * KQ + 1) * 16);
             if (slds > 64 * 1024) {
                 hipError_t e = ppt == 4
                     ? hipFuncSetAttribute((const void *)spamat_bwd_sparse<VAR, KQ, 4>,
