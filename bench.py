@@ -274,6 +274,47 @@ def e2e_bench(B, dev, iters=5):
     return res
 
 
+def train_leg(dev, B=4, iters=30):
+    """BASELINE config 5 (per-GPU share: 4 pairs of 972x540): SpaMat forward + backward at stages 1-3, mask
+    densities 1.0 and 0.1.  Kernel times: the C-ABI entry points on preallocated buffers (events over
+    back-to-back launches); step time: the same through SpaMatFunction.apply / .backward (allocations and
+    autograd included, no host sync inside the loop).  Backward bytes: 4*B*H*W*(4C + 6)."""
+    import decnet_amd
+    from decnet_amd import ops
+    mod = decnet_amd.SpaMat()
+    res = []
+    for dens in (1.0, 0.1):
+        feats, masks = make_inputs(B, dev, dens, seed=555)
+        row = {"mask_density": dens, "stages": []}
+        step_ms = 0.0
+        for s in (1, 2, 3):
+            C, H, W, D = STAGES[s]
+            L, R = feats[s]
+            rm, tm = masks[s]
+            go = torch.randn(B, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+            o, ss, mc = (torch.empty(B, H, W, device=dev) for _ in range(3))
+            gl, gr = torch.empty_like(L), torch.empty_like(R)
+            with torch.no_grad():
+                tf = time_kernel(lambda: ops.spamat_forward(L, R, rm, tm, o, ss, mc, D), iters)
+                tb = time_kernel(lambda: ops.spamat_backward(L, R, rm, tm, o, ss, mc, go, gl, gr, D), iters)
+            Lg, Rg = L.clone().requires_grad_(), R.clone().requires_grad_()
+
+            def step():
+                Lg.grad = Rg.grad = None
+                mod(Lg, Rg, rm, tm, D).backward(go)
+            ts = time_kernel(step, iters)
+            nb = 4.0 * B * H * W * (4 * C + 6)
+            row["stages"].append({"stage": s, "fwd_kernel_ms": tf, "bwd_kernel_ms": tb, "autograd_step_ms": ts,
+                                  "bwd_GBps": nb / tb / 1e6, "bwd_frac_hbm": nb / tb / 1e6 / HBM_PEAK_GBS})
+            step_ms += ts
+        row["fwd_bwd_ms"] = step_ms
+        row["pairs_per_s"] = B / step_ms * 1e3
+        res.append(row)
+    return {"workload": "BASELINE config 5 per-GPU share: SpaMat forward+backward, stages 1-3, "
+                        "%d pairs 972x540 max_disp 216" % B,
+            "by_density": res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +328,8 @@ def main():
     ap.add_argument("--no-density-sweep", action="store_true",
                     help="skip the extra cost-volume timings at mask densities 0.3 .. 0.02 (PMC passes: keeps "
                          "every launch of a kernel the same work)")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the extra 'train' object (config 5: SpaMat forward+backward, stages 1-3)")
     ap.add_argument("--e2e", action="store_true", help="(default at 1 GPU) see --no-e2e")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra 'e2e' object: the whole inference graph (decnet_amd.model: the 2-D "
@@ -439,6 +482,11 @@ def main():
         if sparse:
             out["roofline_costvol_sparse"] = sparse
             out["roofline_costvol_sparse"]["by_density"] = by_density
+        if world == 1 and not args.no_train and args.config == 2:
+            try:
+                out["train"] = train_leg(dev)
+            except Exception as e:
+                out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not args.no_e2e:
             try:
                 out["e2e"] = e2e_bench(B, dev)
