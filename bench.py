@@ -401,19 +401,19 @@ def main():
         s0_ms = sum(e["s0_beg"].elapsed_time(e["s0_end"]) for e in ev) / len(ev)
         with torch.no_grad():
             cv = hp.stage0._cv[next(iter(hp.stage0._cv))]
-            P = hp.reg.prepare()
+            P = hp.reg.prepare(D0)
             from decnet_amd import _lib
             from decnet_amd.stage0 import conv_algo, WINO_VARIANT
             L = _lib.lib()
             a, b, _ = hp.reg._workspace(dev, cv.numel())
             st = torch.cuda.current_stream().cuda_stream
             p0 = P[0]
-            if conv_algo() in WINO_VARIANT:
+            if conv_algo(D0) in WINO_VARIANT:
                 # one Conv3d layer = input transform + batched GEMMs (one per transform point) + output
                 # transform; the GEMM kernel (wino_gemm) is the dominant kernel of the step
-                var = WINO_VARIANT[conv_algo()]
-                oh, npts = (2, 64) if var == 0 else (4, 144)
-                nt = B * ((D0 + 1) // 2) * ((H0 + oh - 1) // oh) * ((W0 + oh - 1) // oh)
+                var = WINO_VARIANT[conv_algo(D0)]
+                od, oh, npts = ((2, 2, 64), (2, 4, 144), (4, 4, 216))[var]
+                nt = B * ((D0 + od - 1) // od) * ((H0 + oh - 1) // oh) * ((W0 + oh - 1) // oh)
                 wsp = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D0, H0, W0, C0, C0, var), device=dev)
                 cp = (C0 + 15) // 16 * 16
                 V, Mw = wsp[:npts * nt * cp], wsp[npts * nt * cp:]
@@ -424,7 +424,7 @@ def main():
                     V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, var, st), 60)
                 kern_flop = 2.0 * npts * nt * C0 * C0
                 kern_name = "wino_gemm (%d x [%d x %d] x [%d x %d], %s Conv3d 216->216)" % (
-                    npts, nt, C0, C0, C0, "Winograd F(2,3)^3" if var == 0 else "Winograd F(2,3)xF(4,3)^2")
+                    npts, nt, C0, C0, C0, ("Winograd F(2,3)^3", "Winograd F(2,3)xF(4,3)^2", "Winograd F(4,3)^3")[var])
                 tkey = "wino_gemm"
             else:
                 conv_ms = layer_ms = time_kernel(lambda: L.decnet_conv3d_bn_act(

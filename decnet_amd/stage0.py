@@ -24,16 +24,23 @@ from .ops import _chk, _stream
 BN_EPS = 1e-5
 
 
-WINO_VARIANT = {"winograd": 0, "winograd4": 1}
+WINO_VARIANT = {"winograd": 0, "winograd4": 1, "winograd444": 2}
 
 
-def conv_algo():
-    """"winograd" (default: F(2,3) on D,H,W, 3.4x fewer multiplications), "winograd4" (F(2,3) on D,
-    F(4,3) on H and W, 6x fewer) or "direct" (27-tap implicit GEMM); DECNET_CONV_ALGO overrides.
-    All are fp32 on the matrix cores; they differ by fp32 rounding only (~1e-6 / ~6e-6 relative)."""
-    a = os.environ.get("DECNET_CONV_ALGO", "winograd4").lower()
-    if a not in ("winograd", "winograd4", "direct"):
-        raise ValueError("DECNET_CONV_ALGO must be 'winograd', 'winograd4' or 'direct'")
+def conv_algo(D=None):
+    """The Conv3d algorithm of the 216-channel layers.  DECNET_CONV_ALGO = "winograd" (F(2,3) on D, H, W:
+    3.4x fewer multiplications than the 27-tap sum), "winograd4" (F(2,3) on D, F(4,3) on H, W: 6x),
+    "winograd444" (F(4,3) on all three: 8x) or "direct" (27-tap implicit GEMM).  Unset: winograd444
+    where the depth tiles of 4 pay (D = 8 or 10 at stage 0 of the shipped configurations), winograd4
+    for shallow volumes.  All are fp32 on the matrix cores and differ by fp32 rounding only
+    (tests/conv_numerics.py: 1.7e-6 / 3.0e-6 / 5.7e-6 / 2.9e-6 of max|y| after the 8 layers)."""
+    a = os.environ.get("DECNET_CONV_ALGO", "auto").lower()
+    if a == "auto":
+        if D is None:
+            return "winograd444"
+        return "winograd444" if 216 * ((D + 3) // 4) <= 0.92 * 144 * ((D + 1) // 2) else "winograd4"
+    if a not in ("winograd", "winograd4", "winograd444", "direct"):
+        raise ValueError("DECNET_CONV_ALGO must be 'winograd', 'winograd4', 'winograd444' or 'direct'")
     return a
 
 
@@ -158,10 +165,11 @@ class CostRegNetNoDown(nn.Module):
                 k.append((t.data_ptr(), t._version))
         return tuple(k)
 
-    def prepare(self):
+    def prepare(self, D=None):
         """Repack the 7 wide Conv3d weights to [27,Ci,CoP] on the device and fold eval-mode
-        BatchNorm into per-channel scale/shift.  Cached until a parameter changes."""
-        algo = conv_algo()
+        BatchNorm into per-channel scale/shift.  Cached until a parameter (or, through the choice
+        of algorithm, the depth D of the volume) changes."""
+        algo = conv_algo(D)
         key = (algo,) + self._key()
         if self._packed is not None and key == self._packed_key:
             return self._packed
@@ -239,7 +247,8 @@ class CostRegNetNoDown(nn.Module):
                                       ".eval() and run under torch.no_grad()")
         _chk("cost volume", x)
         B, D, H, W, C = x.shape
-        P = self.prepare()
+        algo = conv_algo(D)
+        P = self.prepare(D)
         c_true = int(self.units()[0].conv.weight.shape[1])
         if C == c_true and P[0]["Ci"] != C:             # channel count not a multiple of 4: zero pad
             x = torch.nn.functional.pad(x, (0, P[0]["Ci"] - C))
@@ -252,10 +261,10 @@ class CostRegNetNoDown(nn.Module):
         reg = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_reg else None
         pred = torch.empty((B, H, W), dtype=torch.float32, device=dev)
 
-        wino = conv_algo() in WINO_VARIANT
+        wino = algo in WINO_VARIANT
         wsp = None
         if wino:
-            var = WINO_VARIANT[conv_algo()]
+            var = WINO_VARIANT[algo]
             n = L.decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, var)
             wsp = self._ws.get(("wino", dev))
             if wsp is None or wsp.numel() < n:

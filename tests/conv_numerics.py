@@ -50,7 +50,7 @@ def main():
             u.bn.weight.data, u.bn.bias.data = p["bn"][0].clone(), p["bn"][1].clone()
             u.bn.running_mean.data, u.bn.running_var.data = p["bn"][2].clone(), p["bn"][3].clone()
         reg = reg.to(dev).eval()
-        for algo in ("direct", "winograd", "winograd4"):
+        for algo in ("direct", "winograd", "winograd4", "winograd444"):
             os.environ["DECNET_CONV_ALGO"] = algo
             with torch.no_grad():
                 pred, r = decnet_amd.Stage0(reg)(left.to(dev), right.to(dev), D, return_reg=True)

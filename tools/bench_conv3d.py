@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--ci", type=int, default=216)
     ap.add_argument("--co", type=int, default=216)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--algo", default="direct", choices=["direct", "winograd", "winograd4"])
+    ap.add_argument("--algo", default="direct", choices=["direct", "winograd", "winograd4", "winograd444"])
     a = ap.parse_args()
     D, H, W = map(int, a.shape.split(","))
     B, Ci, Co = a.batch, a.ci, a.co
@@ -34,7 +34,7 @@ def main():
     sc, sh = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
     y = torch.empty(B, D, H, W, Co, device=dev)
 
-    var = {"winograd": 0, "winograd4": 1}.get(a.algo, -1)
+    var = {"winograd": 0, "winograd4": 1, "winograd444": 2}.get(a.algo, -1)
     if a.algo != "direct":
         u = torch.empty(L.decnet_conv3d_wino_weight_floats(Ci, var), device=dev)
         _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), u.data_ptr(), Co, Ci, var, st), "wpack")
