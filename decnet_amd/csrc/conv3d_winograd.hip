@@ -44,6 +44,12 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+#ifndef DECNET_WINO_OUT_STREAM
+#define DECNET_WINO_OUT_STREAM 1
+#endif
+#ifndef DECNET_WINO_KSPLIT
+#define DECNET_WINO_KSPLIT 0
+#endif
 constexpr int W_BN = 224;      // co rows of U^T per transform point: 14 MFMA tiles of 16
 __host__ __device__ constexpr int pad16(int c) { return (c + 15) & ~15; }
 
@@ -157,26 +163,23 @@ __device__ __forceinline__ void tile_coords(int t, const Tiling &g, int &b, int 
 // (tile, channel).  Measured alternatives that were not faster: 4 tiles x 16 channels per wave
 // (256-byte V stores, 64-byte x loads), and staging a row of tiles through LDS (phases serialise:
 // two workgroups per CU are not enough to overlap them).
-template <int TD, int TH, int TW>
-__global__ __launch_bounds__(256) void wino_input_transform(const float *__restrict__ x,
-                                                            float *__restrict__ V, Tiling g, int C,
-                                                            int t_lo, int nt, int x_bytes) {
-    const int KC = (C + 15) >> 4;
-    // workgroup = one tile, all channels (a wave = 64 consecutive channels: whole cache lines of x);
-    // XCD aware: ids equal mod 8 (one XCD, one L2) walk a contiguous range of tiles, so the halo
-    // shared by neighbouring tiles and the second half of V's 128-byte lines meet in the same L2
-    const int per_xcd = (nt + 7) >> 3;
-    const int tl = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int c = blockIdx.y * blockDim.x + threadIdx.x, kc = c >> 4;   // blockIdx.y > 0 only if C > 256
-    if ((int)(blockIdx.x >> 3) >= per_xcd || tl >= nt || c >= C) return;
+// KS = 2 (tiles 6 wide): two threads share a (tile, channel); each loads all of it, keeps only ITS
+// three W-transformed columns and finishes those.  A 6x6x6 tile in one thread is 216 live values:
+// 257 registers, one wave per SIMD, 2.8 lock-step rounds of waves (0.053 ms for 179 MB); halved it
+// is 108 values and three waves per SIMD; the doubled loads hit in L1/L2.
+template <int TD, int TH, int TW, int KS, int HALF>
+__device__ __forceinline__ void wino_input_body(const float *__restrict__ x, float *__restrict__ V, const Tiling &g,
+                                                int C, int t_lo, int nt, int x_bytes, int tl, int c) {
+    constexpr int KW = TW / KS, K0 = HALF * KW;
+    const int KC = (C + 15) >> 4, kc = c >> 4;
     int b, z0, y0, x0;
     tile_coords<TD - 2, TH - 2, TW - 2>(t_lo + tl, g, b, z0, y0, x0);
     // branch-free halo: out-of-volume taps are sent past the end of the buffer and read as zeros, so
-    // all TD*TH*TW loads of a thread are in flight together (with branches the compiler waits for
-    // every row of loads before the next)
+    // the loads of a thread are in flight together (with branches the compiler waits for every row
+    // of loads before the next)
     constexpr int OOB = 0x7fffffff;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
-    float d[TD][TH][TW];
+    float d[TD][TH][KW];
 #pragma unroll
     for (int i = 0; i < TD; ++i) {
         const int z = z0 - 1 + i;
@@ -185,25 +188,25 @@ __global__ __launch_bounds__(256) void wino_input_transform(const float *__restr
             const int y = y0 - 1 + jj;
             const bool okzy = (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H;
             const int row = ((((b * g.D + z) * g.H + y) * g.W + x0 - 1) * C + c) * 4;
+            float r[TW];
 #pragma unroll
             for (int k = 0; k < TW; ++k) {
                 const bool ok = okzy && (unsigned)(x0 - 1 + k) < (unsigned)g.W;
 #if DECNET_WINO_ABLATE == 7
-                d[i][jj][k] = ok ? (float)(k + i) : 0.f;
+                r[k] = ok ? (float)(k + i) : 0.f;
 #else
-                d[i][jj][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, ok ? row + k * C * 4 : OOB, 0, 0));
+                r[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, ok ? row + k * C * 4 : OOB, 0, 0));
 #endif
             }
+            bt_1d<TW>(r);
+#pragma unroll
+            for (int k = 0; k < KW; ++k) d[i][jj][k] = r[K0 + k];
         }
     }
 #pragma unroll
     for (int i = 0; i < TD; ++i)
 #pragma unroll
-        for (int jj = 0; jj < TH; ++jj) bt_1d<TW>(d[i][jj]);
-#pragma unroll
-    for (int i = 0; i < TD; ++i)
-#pragma unroll
-        for (int k = 0; k < TW; ++k) {
+        for (int k = 0; k < KW; ++k) {
             float v[TH];
 #pragma unroll
             for (int jj = 0; jj < TH; ++jj) v[jj] = d[i][jj][k];
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void wino_input_transform(const float *__restr
 #pragma unroll
     for (int jj = 0; jj < TH; ++jj)
 #pragma unroll
-        for (int k = 0; k < TW; ++k) {
+        for (int k = 0; k < KW; ++k) {
             float v[TD];
 #pragma unroll
             for (int i = 0; i < TD; ++i) v[i] = d[i][jj][k];
@@ -230,49 +233,64 @@ __global__ __launch_bounds__(256) void wino_input_transform(const float *__restr
         for (int jj = 0; jj < TH; ++jj)
 #pragma unroll
 #if DECNET_WINO_ABLATE == 8
-            for (int k = 0; k < TW; ++k) { if (d[i][jj][k] == 12345.678f) o[(size_t)((i * TH + jj) * TW + k) * xs] = d[i][jj][k]; }
+            for (int k = 0; k < KW; ++k) { if (d[i][jj][k] == 12345.678f) o[(size_t)((i * TH + jj) * TW + K0 + k) * xs] = d[i][jj][k]; }
 #else
-            for (int k = 0; k < TW; ++k) o[(size_t)((i * TH + jj) * TW + k) * xs] = d[i][jj][k];
+            for (int k = 0; k < KW; ++k) o[(size_t)((i * TH + jj) * TW + K0 + k) * xs] = d[i][jj][k];
 #endif
 }
 
-// ------------------------------ output transform + epilogue -----------------------------
+template <int TD, int TH, int TW, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino_input_transform(const float *__restrict__ x,
+                                                            float *__restrict__ V, Tiling g, int C,
+                                                            int t_lo, int nt, int x_bytes) {
+    // workgroup = one tile (one half of it for KS = 2), all channels (a wave = 64 consecutive channels:
+    // whole cache lines of x); XCD aware: ids equal mod 8 (one XCD, one L2) walk a contiguous range of
+    // tiles, so the halo shared by neighbouring tiles, the two halves of a tile and the second half
+    // of V's 128-byte lines meet in the same L2
+    const int per_xcd = (nt + 7) >> 3;
+    const int tl = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int half = blockIdx.y % KS, cblk = blockIdx.y / KS;
+    const int c = cblk * blockDim.x + threadIdx.x;                  // cblk > 0 only if C > 256
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tl >= nt || c >= C) return;
+    if (KS == 1 || half == 0) wino_input_body<TD, TH, TW, KS, 0>(x, V, g, C, t_lo, nt, x_bytes, tl, c);
+    else wino_input_body<TD, TH, TW, KS, KS - 1>(x, V, g, C, t_lo, nt, x_bytes, tl, c);
+}
+
 // M[xi][co/16][tile - t_lo][co%16] -> y: A^T along W, H, D, then BN scale/shift, ReLU, + residual
 // (CostRegNetNoDown.forward submodule.py:656).  Thread mapping as the input transform.
-template <int TD, int TH, int TW>
-__global__ __launch_bounds__(256) void wino_output_transform(
+template <int TD, int TH, int TW, int KS, int HALF>
+__device__ __forceinline__ void wino_output_body(
     const float *__restrict__ M, const float *__restrict__ scale, const float *__restrict__ shift,
-    const float *__restrict__ residual, float *__restrict__ y, Tiling g, int Co, int relu, int t_lo,
-    int nt, int y_bytes) {
-    constexpr int OD = TD - 2, OH = TH - 2, OW = TW - 2;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int CG = (Co + 15) >> 4;
-    const size_t q = idx >> 4;
-    const int cg = (int)(q / nt), tl = (int)(q - (size_t)cg * nt);
-    const int co = cg * 16 + (int)(idx & 15);
-    if (cg >= CG || co >= Co) return;
+    const float *__restrict__ residual, float *__restrict__ y, const Tiling &g, int Co, int relu, int t_lo,
+    int nt, int y_bytes, int cg, int tl, int lane16) {
+    constexpr int OD = TD - 2, OH = TH - 2, OW = TW - 2, OWH = OW / KS, X0 = HALF * OWH;
+    const int CG = (Co + 15) >> 4, co = cg * 16 + lane16;
     int b, z0, y0, x0;
     tile_coords<OD, OH, OW>(t_lo + tl, g, b, z0, y0, x0);
-    const float *mp = M + ((size_t)cg * nt + tl) * 16 + (idx & 15);
+    const float *mp = M + ((size_t)cg * nt + tl) * 16 + lane16;
     const size_t xs = (size_t)CG * nt * 16;
-    float a[TD][TH][OW], bb[TD][OH][OW];
+    float a[TD][TH][OWH], bb[TD][OH][OWH];
 #pragma unroll
     for (int i = 0; i < TD; ++i)
 #pragma unroll
         for (int jj = 0; jj < TH; ++jj) {
-            float m[TW];
+            float m[TW], o[OW];
 #pragma unroll
 #if DECNET_WINO_ABLATE == 7
             for (int k = 0; k < TW; ++k) m[k] = (float)(k + i + jj + tl);
 #else
             for (int k = 0; k < TW; ++k) m[k] = mp[(size_t)((i * TH + jj) * TW + k) * xs];
 #endif
-            at_1d<TW>(m, a[i][jj]);
+            at_1d<TW>(m, o);
+#pragma unroll
+            for (int k = 0; k < OWH; ++k) a[i][jj][k] = o[X0 + k];
+            // at most two depth planes of loads in flight: 216 loads at once need 380 registers
+            if (TD * TH * TW > 160 && jj == TH - 1 && (i & 1)) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
     for (int i = 0; i < TD; ++i)
 #pragma unroll
-        for (int k = 0; k < OW; ++k) {
+        for (int k = 0; k < OWH; ++k) {
             float m[TH], o[OH];
 #pragma unroll
             for (int jj = 0; jj < TH; ++jj) m[jj] = a[i][jj][k];
@@ -286,41 +304,170 @@ __global__ __launch_bounds__(256) void wino_output_transform(
     constexpr int OOB = 0x7fffffff;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(residual ? residual : y), 0, y_bytes, 0x00020000);
-    float out[OD][OH][OW], res[OD][OH][OW];
+    // the epilogue runs in groups of JG output rows: the residual loads of a group are in flight
+    // together, and a 4x4x4 tile does not need 64 outputs + 64 residuals live next to bb
+    constexpr int JG = (OD * OH * OWH > 32) ? 2 : OH;
 #pragma unroll
-    for (int jj = 0; jj < OH; ++jj)
+    for (int j0 = 0; j0 < OH; j0 += JG) {
+        float out[OD][JG][OWH], res[OD][JG][OWH];
 #pragma unroll
-        for (int k = 0; k < OW; ++k) {
-            float m[TD], o[OD];
+        for (int jj = 0; jj < JG; ++jj)
 #pragma unroll
-            for (int i = 0; i < TD; ++i) m[i] = bb[i][jj][k];
-            at_1d<TD>(m, o);
+            for (int k = 0; k < OWH; ++k) {
+                float m[TD], o[OD];
 #pragma unroll
-            for (int i = 0; i < OD; ++i) {
-                const int z = z0 + i, yy = y0 + jj, xx = x0 + k;
-                const int off = z < g.D && yy < g.H && xx < g.W
-                                    ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
-                res[i][jj][k] = residual ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, off, 0, 0)) : 0.f;
-                float v = fmaf(o[i], sc, sh);
-                if (relu) v = fmaxf(v, 0.f);
-                out[i][jj][k] = v;
+                for (int i = 0; i < TD; ++i) m[i] = bb[i][j0 + jj][k];
+                at_1d<TD>(m, o);
+#pragma unroll
+                for (int i = 0; i < OD; ++i) {
+                    const int z = z0 + i, yy = y0 + j0 + jj, xx = x0 + X0 + k;
+                    const int off = z < g.D && yy < g.H && xx < g.W
+                                        ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
+                    res[i][jj][k] = residual ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, off, 0, 0)) : 0.f;
+                    float v = fmaf(o[i], sc, sh);
+                    if (relu) v = fmaxf(v, 0.f);
+                    out[i][jj][k] = v;
+                }
             }
-        }
+#pragma unroll
+        for (int i = 0; i < OD; ++i)
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                for (int k = 0; k < OWH; ++k) {
+                    const int z = z0 + i, yy = y0 + j0 + jj, xx = x0 + X0 + k;
+#if DECNET_WINO_ABLATE == 8
+                    const int off = OOB;
+#else
+                    const int off = z < g.D && yy < g.H && xx < g.W
+                                        ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(out[i][jj][k] + res[i][jj][k]), yr, off, 0, 0);
+                }
+        if (JG < OH) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// A^T of F(4,3) / F(2,3) as a table, for the plane-streaming output transform below
+__constant__ float AT6_TAB[6][4] = {{1.f, 0.f, 0.f, 0.f},       {1.f, 0.75f, 0.5625f, 0.421875f},
+                                    {1.f, -0.75f, 0.5625f, -0.421875f}, {1.f, 1.5f, 2.25f, 3.375f},
+                                    {1.f, -1.5f, 2.25f, -3.375f},  {0.f, 0.f, 0.f, 1.f}};
+
+// 6x6x6 tiles: the depth planes of M stream through two 36-value buffers (plane i + 1 in flight while
+// plane i is reduced 36 -> 16 by the W and H passes) and the D pass is an accumulation
+// out[z] += A^T[z][i] * plane_i, so a thread never holds more than 64 accumulators + 72 loads
+// (the all-in-registers form above needs 337 registers for 216 points: one wave per SIMD).
+template <int TH, int TW>
+__device__ __forceinline__ void wino_output_stream6(
+    const float *__restrict__ M, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ residual, float *__restrict__ y, const Tiling &g, int Co, int relu, int t_lo,
+    int nt, int y_bytes, int cg, int tl, int lane16) {
+    constexpr int TD = 6, OD = 4, OH = TH - 2, OW = TW - 2;
+    const int CG = (Co + 15) >> 4, co = cg * 16 + lane16;
+    int b, z0, y0, x0;
+    tile_coords<OD, OH, OW>(t_lo + tl, g, b, z0, y0, x0);
+    const float *mp = M + ((size_t)cg * nt + tl) * 16 + lane16;
+    const size_t xs = (size_t)CG * nt * 16, ps = xs * TH * TW;       // point stride, plane stride
+    float acc[OD][OH][OW];
 #pragma unroll
     for (int i = 0; i < OD; ++i)
 #pragma unroll
         for (int jj = 0; jj < OH; ++jj)
 #pragma unroll
+            for (int k = 0; k < OW; ++k) acc[i][jj][k] = 0.f;
+    float p0[TH][TW], p1[TH][TW];
+    auto load_plane = [&](float (&p)[TH][TW], const float *base) {
+#pragma unroll
+        for (int jj = 0; jj < TH; ++jj)
+#pragma unroll
+            for (int k = 0; k < TW; ++k) p[jj][k] = base[(size_t)(jj * TW + k) * xs];
+    };
+    auto consume = [&](float (&p)[TH][TW], int i) {
+        float a[TH][OW], h[OH][OW];
+#pragma unroll
+        for (int jj = 0; jj < TH; ++jj) at_1d<TW>(p[jj], a[jj]);
+#pragma unroll
+        for (int k = 0; k < OW; ++k) {
+            float m[TH], o[OH];
+#pragma unroll
+            for (int jj = 0; jj < TH; ++jj) m[jj] = a[jj][k];
+            at_1d<TH>(m, o);
+#pragma unroll
+            for (int jj = 0; jj < OH; ++jj) h[jj][k] = o[jj];
+        }
+        const float c0 = AT6_TAB[i][0], c1 = AT6_TAB[i][1], c2 = AT6_TAB[i][2], c3 = AT6_TAB[i][3];
+#pragma unroll
+        for (int jj = 0; jj < OH; ++jj)
+#pragma unroll
+            for (int k = 0; k < OW; ++k) {
+                acc[0][jj][k] = fmaf(c0, h[jj][k], acc[0][jj][k]);
+                acc[1][jj][k] = fmaf(c1, h[jj][k], acc[1][jj][k]);
+                acc[2][jj][k] = fmaf(c2, h[jj][k], acc[2][jj][k]);
+                acc[3][jj][k] = fmaf(c3, h[jj][k], acc[3][jj][k]);
+            }
+    };
+    load_plane(p0, mp);
+#pragma unroll 1
+    for (int i = 0; i < TD; i += 2) {
+        load_plane(p1, mp + (size_t)(i + 1) * ps);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(p0, i);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < TD) load_plane(p0, mp + (size_t)(i + 2) * ps);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(p1, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const float sc = scale[co], sh = shift[co];
+    constexpr int OOB = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *)(residual ? residual : y), 0, y_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < OD; ++i) {                      // one output depth plane at a time: 16 residual loads in flight
+        float res[OH][OW];
+        int off[OH][OW];
+#pragma unroll
+        for (int jj = 0; jj < OH; ++jj)
+#pragma unroll
             for (int k = 0; k < OW; ++k) {
                 const int z = z0 + i, yy = y0 + jj, xx = x0 + k;
-#if DECNET_WINO_ABLATE == 8
-                const int off = OOB;
-#else
-                const int off = z < g.D && yy < g.H && xx < g.W
-                                    ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
-#endif
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(out[i][jj][k] + res[i][jj][k]), yr, off, 0, 0);
+                off[jj][k] = z < g.D && yy < g.H && xx < g.W ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
+                res[jj][k] = residual ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, off[jj][k], 0, 0)) : 0.f;
             }
+#pragma unroll
+        for (int jj = 0; jj < OH; ++jj)
+#pragma unroll
+            for (int k = 0; k < OW; ++k) {
+                float v = fmaf(acc[i][jj][k], sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+#if DECNET_WINO_ABLATE == 8
+                off[jj][k] = OOB;
+#endif
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v + res[jj][k]), yr, off[jj][k], 0, 0);
+            }
+    }
+}
+
+// KS = 2: two threads per (tile, co), each finishing one half of the output columns (see the input
+// transform); blockIdx.y = half.
+template <int TD, int TH, int TW, int KS>
+__global__ __launch_bounds__(256) void wino_output_transform(
+    const float *__restrict__ M, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ residual, float *__restrict__ y, Tiling g, int Co, int relu, int t_lo,
+    int nt, int y_bytes) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int CG = (Co + 15) >> 4;
+    const size_t q = idx >> 4;
+    const int cg = (int)(q / nt), tl = (int)(q - (size_t)cg * nt);
+    if (cg >= CG || cg * 16 + (int)(idx & 15) >= Co) return;
+    if (TD == 6 && KS == 1 && DECNET_WINO_OUT_STREAM) {
+        wino_output_stream6<TH, TW>(M, scale, shift, residual, y, g, Co, relu, t_lo, nt, y_bytes, cg, tl, (int)(idx & 15));
+        return;
+    }
+    if (KS == 1 || blockIdx.y == 0)
+        wino_output_body<TD, TH, TW, KS, 0>(M, scale, shift, residual, y, g, Co, relu, t_lo, nt, y_bytes, cg, tl, (int)(idx & 15));
+    else
+        wino_output_body<TD, TH, TW, KS, KS - 1>(M, scale, shift, residual, y, g, Co, relu, t_lo, nt, y_bytes, cg, tl, (int)(idx & 15));
 }
 
 // ------------------------------ batched GEMM  M[xi] = V[xi] * U[xi] ----------------------
@@ -721,6 +868,7 @@ int conv_variant(const float *x, const float *u, const float *scale, const float
                  const float *residual, float *y, float *workspace, int B, int D, int H, int W, int Ci,
                  int Co, int relu, hipStream_t s) {
     constexpr int TD = OD + 2, TH = OH + 2, TW = OW + 2, NP = TD * TH * TW;
+    constexpr int KS = (TW == 6 && DECNET_WINO_KSPLIT) ? 2 : 1;      // threads per (tile, channel) in the transforms
     Tiling g{D, H, W, ceil_div(D, OD), ceil_div(H, OH), ceil_div(W, OW)};
     const double Td = (double)B * g.Td * g.Th * g.Tw;
     if (Td >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
@@ -732,15 +880,15 @@ int conv_variant(const float *x, const float *u, const float *scale, const float
         const int nt = T - t_lo < ct ? T - t_lo : ct;
         const int x_bytes = (int)((size_t)B * D * H * W * Ci * 4);
         const int ith = Ci >= 256 ? 256 : (Ci + 63) / 64 * 64;
-        hipLaunchKernelGGL((wino_input_transform<TD, TH, TW>),
-                           dim3((unsigned)(8 * ((nt + 7) / 8)), (unsigned)ceil_div(Ci, ith)), dim3(ith), 0, s, x, V,
-                           g, Ci, t_lo, nt, x_bytes);
+        hipLaunchKernelGGL((wino_input_transform<TD, TH, TW, KS>),
+                           dim3((unsigned)(8 * ((nt + 7) / 8)), (unsigned)(KS * ceil_div(Ci, ith))), dim3(ith), 0, s,
+                           x, V, g, Ci, t_lo, nt, x_bytes);
         int rc = decnet_launch_status();
         if (rc) return rc;
         if ((rc = gemm_dispatch(V, u, M, nt, Ci, Co, NP, s))) return rc;
         const size_t n = (size_t)nt * pad16(Co);
-        hipLaunchKernelGGL((wino_output_transform<TD, TH, TW>), dim3((unsigned)((n + 255) / 256)), dim3(256),
-                           0, s, M, scale, shift, residual, y, g, Co, relu, t_lo, nt,
+        hipLaunchKernelGGL((wino_output_transform<TD, TH, TW, KS>), dim3((unsigned)((n + 255) / 256), KS),
+                           dim3(256), 0, s, M, scale, shift, residual, y, g, Co, relu, t_lo, nt,
                            (int)((size_t)B * D * H * W * Co * 4));
         if ((rc = decnet_launch_status())) return rc;
     }
