@@ -108,6 +108,7 @@ class HotPath:
         self.gbuf, self.pending, self.k = [None, None], [None, None], 0
         self.side = None
         self.ev = None
+        self.overlap = True                             # --no-overlap: everything in order on one stream
 
     def drain(self):
         """Wait for the all-gathers still in flight (end of a timed region)."""
@@ -123,7 +124,7 @@ class HotPath:
         stream so that the per-stage times are clean."""
         d = self.decnet
         cur = torch.cuda.current_stream()
-        overlap = events is None
+        overlap = events is None and self.overlap
         if overlap:
             if self.side is None:
                 self.side = torch.cuda.Stream()
@@ -328,6 +329,10 @@ def main():
     ap.add_argument("--no-density-sweep", action="store_true",
                     help="skip the extra cost-volume timings at mask densities 0.3 .. 0.02 (PMC passes: keeps "
                          "every launch of a kernel the same work)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run SpaMat/SpaVar after stage 0 on the same stream instead of beside it on a second one "
+                         "(profiling runs: a kernel trace then shows every kernel alone on the GPU, the way the "
+                         "roofline leg times it)")
     ap.add_argument("--no-train", action="store_true",
                     help="skip the extra 'train' object (config 5: SpaMat forward+backward, stages 1-3)")
     ap.add_argument("--e2e", action="store_true", help="(default at 1 GPU) see --no-e2e")
@@ -352,6 +357,7 @@ def main():
     set_config(args.config)
     B = args.pairs_per_gpu or DEFAULT_B
     hp = HotPath(B, dev, args.mask_density, world)
+    hp.overlap = not args.no_overlap
 
     def barrier():
         if world > 1:

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-train > $O/bench_profiled.json 2> $O/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-train --no-overlap --no-density-sweep > $O/bench_profiled.json 2> $O/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-train --no-density-sweep > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-train --no-density-sweep > /dev/null 2> $O/pmc_write.err
 cd $R
