@@ -121,7 +121,8 @@ int decnet_conv3d_bn_act(const float *x, const float *w_packed, const float *sca
 /* The same Conv3dUnit by Winograd minimal filtering in fp32 (differs from decnet_conv3d_bn_act by
  * fp32 rounding only).  variant 0: F(2,3) on D,H,W -- 64 transform points, 8 multiplies per output
  * instead of 27, ~1e-6 relative;  variant 1: F(2,3) on D, F(4,3) on H and W -- 144 points, 4.5
- * multiplies per output, ~6e-6 relative.
+ * multiplies per output, ~2e-6 relative;  variant 2: F(4,3) on D, H and W -- 216 points, 3.4 multiplies
+ * per output, ~4e-6 relative (F(4,3) on the points {0, +-3/4, +-3/2, inf}).
  *   u          weights transformed once by decnet_conv3d_wino_pack_weight:
  *              [Co,Ci,3,3,3] -> U^T [points][ceil(Ci/16)][224][16]
  *              (decnet_conv3d_wino_weight_floats floats)

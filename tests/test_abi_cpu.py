@@ -74,3 +74,25 @@ def test_cpu_tensors_are_refused():
     m = torch.ones(1, 3, 4)
     with pytest.raises(decnet_amd.DecnetHipError):
         decnet_amd.SpaMat()(x, x, m, m, 2)
+
+
+def test_conv_algo_choice_and_sizes(lib, monkeypatch):
+    """Host logic of the Conv3d algorithm choice (decnet_amd.stage0.conv_algo) and the size helpers of the
+    three Winograd variants (no GPU call)."""
+    from decnet_amd.stage0 import conv_algo, WINO_VARIANT
+    monkeypatch.delenv("DECNET_CONV_ALGO", raising=False)
+    assert conv_algo(8) == "winograd444" and conv_algo(10) == "winograd444"      # stage 0 of configs 1-5
+    assert conv_algo(2) == "winograd4" and conv_algo(5) == "winograd4" and conv_algo(1) == "winograd4"
+    monkeypatch.setenv("DECNET_CONV_ALGO", "direct")
+    assert conv_algo(8) == "direct"
+    monkeypatch.setenv("DECNET_CONV_ALGO", "fft")
+    with pytest.raises(ValueError):
+        conv_algo(8)
+    lib.decnet_conv3d_wino_weight_floats.restype = ctypes.c_size_t
+    lib.decnet_conv3d_wino_workspace_floats.restype = ctypes.c_size_t
+    for name, pts, (od, oh) in (("winograd", 64, (2, 2)), ("winograd4", 144, (2, 4)), ("winograd444", 216, (4, 4))):
+        v = WINO_VARIANT[name]
+        assert lib.decnet_conv3d_wino_weight_floats(216, v) >= pts * 224 * 224
+        tiles = 8 * -(-8 // od) * -(-20 // oh) * -(-36 // oh)
+        assert lib.decnet_conv3d_wino_workspace_floats(8, 8, 20, 36, 216, 216, v) == pts * tiles * (224 + 224)
+    assert lib.decnet_conv3d_wino_weight_floats(216, 3) == 0

@@ -18,8 +18,8 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--data", default="randn", choices=["randn", "zeros", "relu", "small"])
     a = ap.parse_args()
-    npts = 64 if a.variant == 0 else 144
-    nt = a.nt or (5760 if a.variant == 0 else 1440)
+    npts = (64, 144, 216)[a.variant]
+    nt = a.nt or (5760, 1440, 720)[a.variant]
     C = a.c
     dev = torch.device("cuda:0")
     L = _lib.lib()
