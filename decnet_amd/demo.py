@@ -90,10 +90,6 @@ def build_parser():
 
 
 def build_model(args, device):
-    if not args.use_detail:
-        raise NotImplementedError("use_detail=0 needs the host-side detailDetection masks "
-                                  "(utils/utils.py:483-534, cv2): not on the hot path; every shipped "
-                                  "script runs with --use_detail=1")
     model = get_model(name=args.arch, max_disp=args.max_disp, base_channels=args.base_channels,
                       cost_func=args.cost_func, grad_method=args.grad_method, num_stage=args.num_stage,
                       down_scale=args.down_scale, step=list(map(float, args.step.split(","))),
@@ -112,17 +108,28 @@ def build_model(args, device):
     return model.to(device).eval()
 
 
+def host_masks(padded_img, device):
+    """demo.py:161-167: the three detailDetection masks of one view as [1,H,W] float tensors, coarsest
+    first (stage 1 .. 3).  Used only with --use_detail=0."""
+    from .masks import detail_detection
+    ms = detail_detection(padded_img, scale=3, downsampling_iteration=3, thold=0.3)[::-1]
+    return [torch.from_numpy(m.astype(np.float32))[None].to(device) for m in ms]
+
+
 def run_pair(model, left_img, right_img, device, n_disp=-1):
     """One pair of HxWx3 uint8 RGB arrays -> (uint16 disparity image, seconds)."""
     ori_h, ori_w, _ = left_img.shape
-    left = transform(padding(left_img) / 255).to(device)
-    right = transform(padding(right_img) / 255).to(device)
+    lp, rp = padding(left_img) / 255, padding(right_img) / 255
+    left, right = transform(lp).to(device), transform(rp).to(device)
+    lm = rm = None
+    if not getattr(model, "use_detail", True):
+        lm, rm = host_masks(lp, device), host_masks(rp, device)
     with torch.no_grad():
         if n_disp > 0:
             model.max_disp = int(n_disp)
         torch.cuda.synchronize()
         t0 = time.time()
-        pred = model(left, right)[-1]
+        pred = model(left, right, None, lm, rm)[-1]
         torch.cuda.synchronize()
         dt = time.time() - t0
     return disparity_to_uint16(pred, ori_h, ori_w), dt

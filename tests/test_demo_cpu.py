@@ -35,3 +35,29 @@ def test_uint16_output_and_png_roundtrip(tmp_path):
     demo.write_png16(path, full)
     from PIL import Image
     assert (np.asarray(Image.open(path)) == full).all()
+
+
+def test_host_detail_masks():
+    """decnet_amd.masks.detail_detection (utils/utils.py:483-534 without cv2; parity unpinned): shapes,
+    the INTER_LINEAR quirk of the reference's cv2.resize calls, where the detail lands, flat images."""
+    import numpy as np
+    from decnet_amd.masks import detail_detection, resize_linear, gaussian_blur
+    img = np.zeros((54, 81, 3), np.float32)
+    img[:, 40:] = 1.0                                         # one vertical edge
+    ms = detail_detection(img, scale=3, downsampling_iteration=3, thold=0.3)
+    assert [m.shape for m in ms] == [(54, 81), (18, 27), (6, 9)] and all(m.dtype == bool for m in ms)
+    cols = np.nonzero(ms[0].any(0))[0]
+    assert cols.min() >= 36 and cols.max() <= 43 and ms[0][:, 38:42].all()      # only around the edge
+    assert not ms[0][:, :30].any() and not ms[0][:, 50:].any()
+    # down by 3 = src[3i+1] (half-pixel-centre bilinear with an integer source position)
+    a = np.random.default_rng(0).random((12, 15, 2)).astype(np.float32)
+    assert np.array_equal(resize_linear(a, 4, 5), a[1::3, 1::3])
+    # up by 3 keeps constants and clamps at the border
+    up = resize_linear(a[:2, :2], 6, 6)
+    assert np.allclose(up[0, 0], a[0, 0]) and np.allclose(up[-1, -1], a[1, 1])
+    assert np.allclose(gaussian_blur(np.full((7, 9, 1), 0.25, np.float32), 5), 0.25, atol=1e-6)
+    # flat image: 0/0 -> no detail anywhere (the reference's NaN compares false too)
+    assert not any(m.any() for m in detail_detection(np.full((27, 27, 3), 0.5, np.float32)))
+    # sizes that are not multiples of 27 get the reference's top/left padding, whose mask part is cleared
+    ms = detail_detection(np.random.default_rng(1).random((50, 70, 3)).astype(np.float32))
+    assert ms[0].shape == (54, 81) and not ms[0][:4].any() and not ms[0][:, :11].any()

@@ -98,3 +98,27 @@ def test_demo_counterpart_runs_on_a_directory(tmp_path):
     a = np.asarray(Image.open(str(tmp_path / "out" / "a.png")))
     b = np.asarray(Image.open(str(tmp_path / "out" / "b.png")))
     assert a.shape == (40, 100) and b.shape == (54, 81) and a.dtype == np.uint16
+
+
+def test_demo_with_host_detail_masks(tmp_path):
+    """--use_detail=0: the masks come from the host-side detail detector (decnet_amd/masks.py, reference
+    utils/utils.py:483-534) instead of GenerateSparseMask; the result equals a direct model call with them."""
+    from decnet_amd import demo
+    from decnet_amd.masks import detail_detection
+    rng = np.random.RandomState(1)
+    limg = rng.randint(0, 255, (54, 81, 3)).astype(np.uint8)
+    rimg = np.roll(limg, -3, axis=1)
+    args = demo.build_parser().parse_args(["--base_channels", "2", "--max_disp", "54", "--use_detail", "0"])
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = demo.build_model(args, dev)
+    assert model.use_detail is False
+    img, _ = demo.run_pair(model, limg, rimg, dev)
+    assert img.shape == (54, 81) and img.dtype == np.uint16
+    lp, rp = demo.padding(limg) / 255, demo.padding(rimg) / 255
+    lm = [torch.from_numpy(m.astype(np.float32))[None].to(dev) for m in detail_detection(lp)[::-1]]
+    rm = [torch.from_numpy(m.astype(np.float32))[None].to(dev) for m in detail_detection(rp)[::-1]]
+    assert [tuple(m.shape) for m in lm] == [(1, 6, 9), (1, 18, 27), (1, 54, 81)]
+    with torch.no_grad():
+        pred = model(demo.transform(lp).to(dev), demo.transform(rp).to(dev), None, lm, rm)[-1]
+    assert np.array_equal(demo.disparity_to_uint16(pred, 54, 81), img)
