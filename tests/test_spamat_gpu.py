@@ -262,3 +262,43 @@ def test_rejects_bad_arguments(dev):
         decnet_amd.SpaMat()(L.double(), R.double(), rm, tm, 4)
     with pytest.raises(ValueError):
         decnet_amd.SpaMat()(L, R, rm[:, :1], tm, 4)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomized_shapes_forward_and_backward(dev, seed):
+    """Random (B, C, H, W, D, densities) around every dispatch boundary of the forward and backward kernels
+    (sparse-row / band, aligned and ragged widths, D above and below W, C of the three compiled K depths
+    and odd ones), several cases per seed, forward (SpaMat, fused SpaVar) and both backward passes."""
+    import decnet_amd
+    rng = np.random.RandomState(1000 + seed)
+    for _ in range(5):
+        C = int(rng.choice([3, 8, 8, 8, 12, 24, 24, 40, 72]))
+        W = int(rng.choice([rng.randint(5, 64), rng.randint(64, 400), 4 * rng.randint(20, 140), rng.randint(400, 700)]))
+        D = int(rng.choice([rng.randint(2, 30), 24, 72, 216, min(270, W + rng.randint(0, 40))]))
+        B, H = int(rng.randint(1, 3)), int(rng.randint(1, 5))
+        pr, pt = (float(rng.choice([0.0, 0.03, 0.1, 0.25, 0.5, 0.9, 1.0])) for _ in range(2))
+        L, R, rm, tm = make_case(int(rng.randint(1 << 30)), B, C, H, W, pr, pt, relu=bool(rng.randint(2)), scale=0.5)
+        tag = dict(B=B, C=C, H=H, W=W, D=D, pr=pr, pt=pt)
+        o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+        dL, dR = L.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+        out = decnet_amd.SpaMatFunction.apply(dL, dR, rm.to(dev), tm.to(dev), D)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), o, rtol=1e-5, atol=3e-4, err_msg=str(tag))
+        g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(seed))
+        gl, gr = oracle.spamat_backward(L, R, rm, tm, o, s, m, g, D)
+        out.backward(g.to(dev))
+        sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+        assert np.abs(dL.grad.cpu().numpy() - gl).max() < 3e-5 * sc, tag
+        assert np.abs(dR.grad.cpu().numpy() - gr).max() < 3e-5 * sc, tag
+        mu = torch.from_numpy(o) + 0.25
+        v, s2, m2 = oracle.spavar_forward(L, R, rm, tm, mu, D)
+        fo, fv, fs, fm = decnet_amd.spamatvar_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
+        np.testing.assert_allclose(fo.cpu().numpy(), o, rtol=1e-5, atol=3e-4, err_msg=str(tag))
+        vo, _, _ = oracle.spavar_forward(L, R, rm, tm, torch.from_numpy(o), D)
+        np.testing.assert_allclose(fv.cpu().numpy(), vo, rtol=2e-4, atol=2e-2, err_msg=str(tag))
+        gl, gr, gd = oracle.spavar_backward(L, R, rm, tm, mu, v, s2, m2, g, D)
+        dL, dR, dmu = L.to(dev).requires_grad_(), R.to(dev).requires_grad_(), mu.to(dev).requires_grad_()
+        decnet_amd.SpaVarFunction.apply(dL, dR, rm.to(dev), tm.to(dev), dmu, D).backward(g.to(dev))
+        sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()), float(np.abs(gd).max()))
+        assert np.abs(dL.grad.cpu().numpy() - gl).max() < 6e-5 * sc, tag
+        assert np.abs(dR.grad.cpu().numpy() - gr).max() < 6e-5 * sc, tag
+        assert np.abs(dmu.grad.cpu().numpy() - gd).max() < 6e-5 * sc, tag
