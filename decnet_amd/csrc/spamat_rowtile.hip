@@ -325,6 +325,122 @@ int set_lds(K kernel, size_t bytes) {
     return DECNET_OK;
 }
 
+// Last resort of the forward pass (C x max_disp beyond any LDS tile, e.g. C = 216 with max_disp = 270):
+// the arithmetic of spamat_fwd_rowtile straight from global memory, one thread per left pixel.
+template <int MODE>
+__global__ __launch_bounds__(256) void spamat_fwd_generic(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
+    float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int B, int C,
+    int H, int W, int D) {
+    const size_t plane = (size_t)H * W, pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (size_t)B * plane) return;
+    if (rmask[pix] == 0.f) {
+        if (MODE != MODE_VAR) out[pix] = 0.f;
+        if (MODE != MODE_MAT) var_out[pix] = 0.f;
+        sum_sim[pix] = 0.f;
+        max_cost[pix] = 0.f;
+        return;
+    }
+    const size_t b = pix / plane, rem = pix - b * plane;
+    const int x = (int)(rem % W);
+    const float *l = ref + b * C * plane + rem, *r = tar + b * C * plane + rem;
+    const int cur = x - D + 1 >= 0 ? D : x + 1;
+    auto cost_at = [&](int d) {
+        float cost = 0.f;
+        for (int c = 0; c < C; ++c) cost = fmaf(l[(size_t)c * plane], r[(size_t)c * plane - d], cost);
+        return cost;
+    };
+    float m = 0.000001f;
+    for (int d = 0; d < cur; ++d) {
+        if (tmask[pix - d] == 0.f) continue;
+        const float cost = cost_at(d);
+        if (m < cost) m = cost;
+    }
+    float S = 0.000001f, sd = 0.000001f, mu = 0.f;
+    if (MODE == MODE_VAR) mu = disparity[pix];
+    if (MODE != MODE_VAR) {
+        for (int d = 0; d < cur; ++d) {
+            if (tmask[pix - d] == 0.f) continue;
+            const float e = expf(cost_at(d) - m);
+            sd = fmaf(e, (float)d, sd);
+            S += e;
+        }
+        mu = sd / S;
+        out[pix] = mu;
+    }
+    if (MODE != MODE_MAT) {
+        float S2 = 0.000001f, sv = 0.000001f;
+        for (int d = 0; d < cur; ++d) {
+            if (tmask[pix - d] == 0.f) continue;
+            const float e = expf(cost_at(d) - m), dd = (float)d - mu;
+            sv = fmaf(e * dd, dd, sv);
+            S2 += e;
+        }
+        var_out[pix] = sv / S2;
+        S = S2;
+    }
+    sum_sim[pix] = S;
+    max_cost[pix] = m;
+}
+
+// Last resort of the backward pass: no LDS tile, so no limit on C x max_disp (the row-tile kernels need
+// (C+1)*(D-1) floats of LDS: C = 72 with max_disp = 270 does not fit; the shipped configurations never
+// get here).  One thread per pixel of the own side (SIDE 0: left pixel -> grad_ref (, grad_disparity);
+// SIDE 1: right pixel -> grad_tar), 8 channels of gradient per pass over the disparities, the cost
+// recomputed from global memory in each pass: the reference's arithmetic (SM_kernel.cu:143-195, 300-355;
+// SV_kernel.cu:142-325) with C/8 instead of C redundant cost sweeps.
+template <bool VAR, int SIDE>
+__global__ __launch_bounds__(256) void spamat_bwd_generic(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity, const float *__restrict__ out,
+    const float *__restrict__ sum_sim, const float *__restrict__ max_cost,
+    const float *__restrict__ grad_out, float *__restrict__ grad_own, float *__restrict__ grad_disp, int B,
+    int C, int H, int W, int D) {
+    const size_t plane = (size_t)H * W, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * plane) return;
+    const size_t b = idx / plane, rem = idx - b * plane;
+    const int x = (int)(rem % W);
+    const size_t base3 = b * C * plane + rem;
+    const bool on = (SIDE == 0 ? rmask[idx] : tmask[idx]) != 0.f;
+    if (!on) {
+        for (int c = 0; c < C; ++c) grad_own[base3 + (size_t)c * plane] = 0.f;
+        if (VAR && SIDE == 0) grad_disp[idx] = 0.f;
+        return;
+    }
+    const int cur = SIDE == 0 ? (x - D + 1 >= 0 ? D : x + 1) : (x + D <= W ? D : W - x);
+    float gd = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < cur; ++d) {
+            const size_t l2 = SIDE == 0 ? idx : idx + d, r2 = SIDE == 0 ? idx - d : idx;   // left / right pixel
+            if ((SIDE == 0 ? tmask[r2] : rmask[l2]) == 0.f) continue;
+            const float *lp = ref + (SIDE == 0 ? base3 : base3 + d), *rp = tar + (SIDE == 0 ? base3 - d : base3);
+            float cost = 0.f;
+            for (int c = 0; c < C; ++c) cost = fmaf(lp[(size_t)c * plane], rp[(size_t)c * plane], cost);
+            const float e = expf(cost - max_cost[l2]);
+            float wgt;
+            if (VAR) {
+                const float dd = (float)d - disparity[l2];
+                wgt = fmaf(dd, dd, -out[l2]);
+                if (SIDE == 0 && c0 == 0) gd = fmaf(e, dd, gd);
+            } else {
+                wgt = (float)d - out[l2];
+            }
+            const float w = SIDE == 0 ? e * wgt : grad_out[l2] * e * wgt / sum_sim[l2];
+            const float *op = SIDE == 0 ? rp : lp;                                          // the other side's features
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c0 + k < C) acc[k] = fmaf(w, op[(size_t)(c0 + k) * plane], acc[k]);
+        }
+        const float sc = SIDE == 0 ? grad_out[idx] / sum_sim[idx] : 1.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < C) grad_own[base3 + (size_t)(c0 + k) * plane] = acc[k] * sc;
+    }
+    if (VAR && SIDE == 0) grad_disp[idx] = -2.f * grad_out[idx] * gd / sum_sim[idx];
+}
+
 }  // namespace
 
 // ------------------------------- host launchers (internal) ------------------------------
@@ -338,7 +454,20 @@ int decnet_rowtile_forward(int mode, const float *ref, const float *tar, const f
     size_t lds = 0;
     // Ls C*TW + Rs C*(TW+D-1) + Ts (TW+D-1)
     int TW = pick_tw(W, (size_t)2 * C + 1, (size_t)(C + 1) * (D - 1), &lds);
-    if (!TW) return DECNET_ERR_UNSUPPORTED;
+    if (!TW) {                                          // no LDS tile fits: global-memory kernel
+        const size_t n = (size_t)B * H * W;
+        const dim3 g((unsigned)((n + 255) / 256)), blk(256);
+        if (mode == MODE_MAT)
+            hipLaunchKernelGGL(spamat_fwd_generic<MODE_MAT>, g, blk, 0, stream, ref, tar, rmask, tmask, disparity, out,
+                               var_out, sum_sim, max_cost, B, C, H, W, D);
+        else if (mode == MODE_VAR)
+            hipLaunchKernelGGL(spamat_fwd_generic<MODE_VAR>, g, blk, 0, stream, ref, tar, rmask, tmask, disparity, out,
+                               var_out, sum_sim, max_cost, B, C, H, W, D);
+        else
+            hipLaunchKernelGGL(spamat_fwd_generic<MODE_FUSED>, g, blk, 0, stream, ref, tar, rmask, tmask, disparity, out,
+                               var_out, sum_sim, max_cost, B, C, H, W, D);
+        return decnet_launch_status();
+    }
     int tiles = ceil_div(W, TW);
     dim3 grid((unsigned)((size_t)B * H * tiles)), block(TW);
     int rc;
@@ -364,7 +493,23 @@ int decnet_rowtile_backward(int var, const float *ref, const float *tar, const f
     int TWr = pick_tw(W, (size_t)2 * C + 1 + D, (size_t)(C + 1) * (D - 1), &lds_r);
     int planes = var ? 5 : 4;
     int TWt = pick_tw(W, (size_t)2 * C + planes + D, (size_t)(C + planes) * (D - 1), &lds_t);
-    if (!TWr || !TWt) return DECNET_ERR_UNSUPPORTED;
+    if (!TWr || !TWt) {                                 // C x max_disp beyond any LDS tile: global-memory kernels
+        const size_t n = (size_t)B * H * W;
+        if (n >= ((size_t)1 << 31) * 256) return DECNET_ERR_BAD_SHAPE;
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        if (var) {
+            hipLaunchKernelGGL((spamat_bwd_generic<true, 0>), grid, block, 0, stream, ref, tar, rmask, tmask, disparity,
+                               out, sum_sim, max_cost, grad_out, grad_ref, grad_disp, B, C, H, W, D);
+            hipLaunchKernelGGL((spamat_bwd_generic<true, 1>), grid, block, 0, stream, ref, tar, rmask, tmask, disparity,
+                               out, sum_sim, max_cost, grad_out, grad_tar, nullptr, B, C, H, W, D);
+        } else {
+            hipLaunchKernelGGL((spamat_bwd_generic<false, 0>), grid, block, 0, stream, ref, tar, rmask, tmask, disparity,
+                               out, sum_sim, max_cost, grad_out, grad_ref, nullptr, B, C, H, W, D);
+            hipLaunchKernelGGL((spamat_bwd_generic<false, 1>), grid, block, 0, stream, ref, tar, rmask, tmask, disparity,
+                               out, sum_sim, max_cost, grad_out, grad_tar, nullptr, B, C, H, W, D);
+        }
+        return decnet_launch_status();
+    }
     int rc;
     {
         int tiles = ceil_div(W, TWr);

@@ -302,3 +302,33 @@ def test_randomized_shapes_forward_and_backward(dev, seed):
         assert np.abs(dL.grad.cpu().numpy() - gl).max() < 6e-5 * sc, tag
         assert np.abs(dR.grad.cpu().numpy() - gr).max() < 6e-5 * sc, tag
         assert np.abs(dmu.grad.cpu().numpy() - gd).max() < 6e-5 * sc, tag
+
+
+@pytest.mark.parametrize("B,C,H,W,D,p", [(1, 72, 2, 300, 270, 0.5), (1, 216, 2, 280, 270, 0.3), (1, 100, 1, 150, 400, 1.0)])
+def test_shapes_beyond_any_lds_tile(dev, B, C, H, W, D, p):
+    """C x max_disp too large for the band and the row-tile kernels (outside the shipped configurations,
+    inside what the reference's global-memory kernels accept): the global-memory fallbacks, forward and
+    backward, SpaMat and SpaVar."""
+    import decnet_amd
+    L, R, rm, tm = make_case(21, B, C, H, W, p, p, relu=False, scale=0.25)
+    g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(6))
+    o, s_, m = oracle.spamat_forward(L, R, rm, tm, D)
+    gl, gr = oracle.spamat_backward(L, R, rm, tm, o, s_, m, g, D)
+    dL, dR = L.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+    out = decnet_amd.SpaMatFunction.apply(dL, dR, rm.to(dev), tm.to(dev), D)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), o, rtol=1e-5, atol=3e-4)
+    out.backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 3e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 3e-5 * sc
+    mu = torch.from_numpy(o) + 0.25
+    v, s2, m2 = oracle.spavar_forward(L, R, rm, tm, mu, D)
+    gl, gr, gd = oracle.spavar_backward(L, R, rm, tm, mu, v, s2, m2, g, D)
+    dL, dR, dmu = L.to(dev).requires_grad_(), R.to(dev).requires_grad_(), mu.to(dev).requires_grad_()
+    var = decnet_amd.SpaVarFunction.apply(dL, dR, rm.to(dev), tm.to(dev), dmu, D)
+    np.testing.assert_allclose(var.detach().cpu().numpy(), v, rtol=2e-4, atol=2e-2)
+    var.backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()), float(np.abs(gd).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 6e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 6e-5 * sc
+    assert np.abs(dmu.grad.cpu().numpy() - gd).max() < 6e-5 * sc
