@@ -708,7 +708,7 @@ template <int WM, int NPAIR>
 __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_bf16x3(
     const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
     int Co, int np, int swz) {
-    constexpr int TM = 3, TN = 7, OOB = 0x7fffffff, RING = 4, AHEAD = 3;
+    constexpr int TM = 3, TN = 7, OOB = 0x7fffffff, RING = 4;   // ring of 4 operand tiles: tile s + 3 (AHEAD) in flight while s is multiplied
     const int mblocks = gridDim.x, ngroups = gridDim.y;
     int pt = blockIdx.y, mb = blockIdx.x;
     if (swz) {
