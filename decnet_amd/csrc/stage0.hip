@@ -40,13 +40,16 @@ constexpr int B_PITCH = 240;   // == 16 (mod 32): rows kq, kq+1 land on opposite
 __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict__ left,
                                                          const float *__restrict__ right,
                                                          float *__restrict__ cost, int C, int H,
-                                                         int W, int D, int dchunk) {
+                                                         int W, int D, int dchunk, int cgn) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int WP = W | 1;                      // odd pitch: column reads across c are conflict-free
-    float *Ls = smem;                          // [C][WP]
-    float *R0 = Ls + C * WP;                   // [C][WP]   row y0 (zeros if outside)
-    float *R1 = R0 + C * WP;                   // [C][WP]   row y0 + 1
+    // blockIdx.z picks a group of cgn channels (the "cor" volume is elementwise in c): a workgroup per
+    // (row, channel group) stages 3 x cgn x W floats instead of 3 x C x W -- more, smaller workgroups
+    const int c_lo = blockIdx.z * cgn, CN = min(cgn, C - c_lo);
+    float *Ls = smem;                          // [CN][WP]
+    float *R0 = Ls + CN * WP;                  // [CN][WP]  row y0 (zeros if outside)
+    float *R1 = R0 + CN * WP;                  // [CN][WP]  row y0 + 1
     const int b = blockIdx.x / H, y = blockIdx.x - b * H;
     const float cy = (float)y / ((float)(H - 1.0) / 2.0f) - 1.0f;
     const float iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
     const int y0 = (int)fy, y1 = y0 + 1;
     const float wy1 = iy - fy, wy0 = 1.0f - wy1;
     const size_t plane = (size_t)H * W;
-    const float *Lb = left + (size_t)b * C * plane, *Rb = right + (size_t)b * C * plane;
+    const float *Lb = left + ((size_t)b * C + c_lo) * plane, *Rb = right + ((size_t)b * C + c_lo) * plane;
     // no per-element integer division anywhere: a wave stages one channel row at a time, and later
     // owns one (d, x) output column at a time with its lanes across the channels
     const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
@@ -62,12 +65,12 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
     constexpr int U = 9;                       // channel rows in flight per wave (latency, not bandwidth, bounds this)
     for (int x = lane; x < W; x += 64)
-        for (int c0 = wave; c0 < C; c0 += nwaves * U) {
+        for (int c0 = wave; c0 < CN; c0 += nwaves * U) {
             float l[U], r0[U], r1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int c = c0 + u * nwaves;
-                const bool ok = c < C;
+                const bool ok = c < CN;
                 l[u] = ok ? Lb[c * plane + (size_t)y * W + x] : 0.f;
                 r0[u] = ok && vy0 ? Rb[c * plane + (size_t)y0 * W + x] : 0.f;
                 r1[u] = ok && vy1 ? Rb[c * plane + (size_t)y1 * W + x] : 0.f;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int c = c0 + u * nwaves;
-                if (c < C) {
+                if (c < CN) {
                     Ls[c * WP + x] = l[u];
                     R0[c * WP + x] = r0[u];
                     R1[c * WP + x] = r1[u];
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
     __syncthreads();
     // blockIdx.y picks a chunk of disparities (more workgroups than the B*H rows alone)
     const int d_lo = blockIdx.y * dchunk, d_hi = min(D, d_lo + dchunk);
-    float *out = cost + (size_t)b * D * plane * C + (size_t)y * W * C;     // + d*plane*C + x*C + c
+    float *out = cost + (size_t)b * D * plane * C + (size_t)y * W * C + c_lo;     // + d*plane*C + x*C + c
     for (int t = d_lo * W + wave; t < d_hi * W; t += nwaves) {
         const int d = t / W, x = t - d * W;                       // wave-uniform
         float cx = (float)(x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
         bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
         const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
         float *o = out + (size_t)d * plane * C + (size_t)x * C;
-        for (int c = lane; c < C; c += 64) {
+        for (int c = lane; c < CN; c += 64) {
             float l = x >= d ? Ls[c * WP + x] : 0.f;              // submodule.py:506-508
             float r = 0.f;                                        // same tap order as grid_sample
             if (vy0 && vx0) r += R0[c * WP + x0] * w00;
@@ -723,7 +726,11 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
     if ((double)B * D * H * W * C >= 1099511627776.0 || (double)D * W * C >= 2147483648.0 ||
         (double)B * H >= 2147483648.0)
         return DECNET_ERR_BAD_SHAPE;
-    size_t lds = (size_t)3 * C * (W | 1) * 4;
+    // channel groups of <= 128, equal sizes: 216 -> 2 x 108 with 4 disparities per workgroup measured best
+    // (0.031 ms; one workgroup per row with all 216 channels and 8 disparities: 0.046 ms; 4 x 54: 0.044 ms)
+    static const int cg_env = [] { const char *e = getenv("DECNET_COSTVOL_CGROUP"); return e ? atoi(e) : 0; }();
+    const int groups = cg_env > 0 ? ceil_div(C, cg_env) : ceil_div(C, 128), cgn = ceil_div(C, groups);
+    size_t lds = (size_t)3 * cgn * (W | 1) * 4;
     if (lds > DECNET_LDS_BYTES - 1024) return DECNET_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)costvol_cor_ndhwc,
@@ -734,10 +741,11 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
     // expensive part, so a workgroup keeps its rows for as many d as still leaves >= ~1 workgroup per CU
     static const int dc_env = [] { const char *e = getenv("DECNET_COSTVOL_DCHUNK"); return e ? atoi(e) : 0; }();
     int dchunk = 1;
-    while (dchunk < D && (long)B * H * ceil_div(D, 2 * dchunk) >= 160) dchunk *= 2;
+    while (dchunk < D && (long)B * H * ceil_div(C, cgn) * ceil_div(D, 2 * dchunk) >= 512) dchunk *= 2;
     if (dc_env > 0) dchunk = dc_env;
-    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H), (unsigned)ceil_div(D, dchunk)),
-                       dim3(512), lds, (hipStream_t)stream, left, right, cost, C, H, W, D, dchunk);
+    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H), (unsigned)ceil_div(D, dchunk),
+                                               (unsigned)ceil_div(C, cgn)),
+                       dim3(512), lds, (hipStream_t)stream, left, right, cost, C, H, W, D, dchunk, cgn);
     return decnet_launch_status();
 }
 
