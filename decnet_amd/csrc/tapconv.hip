@@ -18,12 +18,19 @@ constexpr int T_BN = 224;          // co rows per tap in U^T (= W_BN of conv3d_w
 
 __global__ __launch_bounds__(256) void nchw_to_chunks(const float *__restrict__ x, float *__restrict__ V, int C,
                                                       int HW, int P) {
-    // thread = (position p, channel c), p fastest: coalesced reads; writes are 4-byte scattered (5 MB tensor)
+    // thread = (position p, 16-channel chunk kc), p fastest: 16 coalesced plane reads, one 64-byte store
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)P * C) return;
-    const int p = (int)(idx % P), c = (int)(idx / P);
+    const int KC = (C + 15) >> 4;
+    if (idx >= (size_t)P * KC) return;
+    const int p = (int)(idx % P), kc = (int)(idx / P);
     const int b = p / HW, i = p - b * HW;
-    V[((size_t)(c >> 4) * P + p) * 16 + (c & 15)] = x[((size_t)b * C + c) * HW + i];
+    const float *xp = x + ((size_t)b * C + kc * 16) * HW + i;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = kc * 16 + j < C ? xp[(size_t)j * HW] : 0.f;
+    float4 *o = reinterpret_cast<float4 *>(V + ((size_t)kc * P + p) * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
 // w [Co][Ci][kk] -> U^T [tap0 + t][ceil(Ci/16)][224][16]
@@ -92,7 +99,7 @@ size_t decnet_tapconv_chunk_floats(int B, int Ci, int H, int W) {
 int decnet_tapconv_to_chunks(const float *x, float *V, int B, int Ci, int H, int W, void *stream) {
     if (!x || !V) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Ci < 1 || H < 1 || W < 1 || (double)B * H * W * Ci >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
-    const size_t n = (size_t)B * H * W * Ci;
+    const size_t n = (size_t)B * H * W * ((Ci + 15) / 16);
     hipLaunchKernelGGL(nchw_to_chunks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, Ci,
                        H * W, B * H * W);
     return decnet_launch_status();
