@@ -406,7 +406,7 @@ def main():
         conv_flop = 2.0 * 27 * C0 * C0 * M                      # direct-convolution flops of one layer
         s0_ms = sum(e["s0_beg"].elapsed_time(e["s0_end"]) for e in ev) / len(ev)
         with torch.no_grad():
-            cv = hp.stage0._cv[next(iter(hp.stage0._cv))]
+            cv = hp.reg.costvol_buffer(dev, B, D0, H0, W0, C0)
             P = hp.reg.prepare(D0)
             from decnet_amd import _lib
             from decnet_amd.stage0 import conv_algo, WINO_VARIANT

@@ -12,6 +12,7 @@ from small spec tables below with the reference's attribute names, so a referenc
 Inference only (``model.eval()``, ``torch.no_grad()``): the reference's training entry point is
 not runnable as shipped.
 """
+import math
 import os
 
 import torch
@@ -460,8 +461,26 @@ class SparseDenseNetRefinementMask(nn.Module):
         self.soft_attention = nn.ModuleList(SoftAttention(ch[i + 1] + 4, base_channels) for i in range(n))
         self.refinement = nn.ModuleList(Refinement(ch[i + 1], base_channels // 2 ** i, i + 1, down_scale)
                                         for i in range(n))
-        # not registered as a submodule (it only wraps cost_regularizer): no duplicate state_dict keys
-        object.__setattr__(self, "_stage0", Stage0(self.cost_regularizer))
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        """SparseDenseNetRefinementMask.py:239-257: He-normal Conv2d / Conv3d weights (fan-out), zero conv
+        biases, unit BatchNorm.  ConvTranspose2d is not a Conv2d: transposed convolutions keep PyTorch's
+        default init, as in the reference.  The sub-nets above are built in the reference's order with
+        the reference's layer shapes, so after ``torch.manual_seed(17)`` (demo.py:70) this yields the
+        reference's from-scratch tensors bit for bit (tests/test_init_cpu.py)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.Conv3d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
 
     def forward(self, left, right, disparity=None, left_mask_list=None, right_mask_list=None,
                 is_check=False, is_eval=False):
@@ -484,7 +503,7 @@ class SparseDenseNetRefinementMask(nn.Module):
             if stage == 0:
                 # get_disp_samples -> GetCostVolume -> CostRegNetNoDown -> disparity_regression
                 # (reference :127-137) as one channels-last pipeline on the matrix cores
-                pred = self._stage0(L, R, cur_max_disp)
+                pred = self.cost_regularizer.stage0(L, R, cur_max_disp)
                 pre_L, pre_R = L, R
                 continue
             if stage >= self.skip_stage_id:                               # reference :143-144

@@ -110,7 +110,15 @@ class GetCostVolume(nn.Module):
             raise NotImplementedError("the gfx950 path implements warp_ope='homgrp', "
                                       "cost_func='cor' (demo.sh / eval.sh)")
         if "disp_samples" in kargs and kargs["disp_samples"] is not None:
-            D = int(kargs["disp_samples"].size(1))      # must be the stage-0 arange samples
+            ds = kargs["disp_samples"]
+            D = int(ds.size(1))
+            # the kernel warps by d = 0 .. D-1 (get_disp_samples, stage 0); any other hypotheses would
+            # silently give a different volume than submodule.py:479-510, so refuse them (one host
+            # sync: this reference-shaped module is not the fast path, Stage0 is)
+            ar = torch.arange(D, dtype=ds.dtype, device=ds.device).view(1, D, 1, 1)
+            if ds.dim() != 4 or not bool((ds == ar).all()):
+                raise NotImplementedError("GetCostVolume on gfx950 takes the stage-0 samples "
+                                          "arange(max_disp) only (submodule.py:389-390)")
         else:
             D = int(kargs["max_disp"])
         cv = costvol_ndhwc(left_feature_map.contiguous(), right_feature_map.contiguous(), D)
@@ -314,6 +322,31 @@ class CostRegNetNoDown(nn.Module):
         reg, _ = self.run_ndhwc(_to_ndhwc(x), want_reg=True, want_pred=False)
         return reg
 
+    def costvol_buffer(self, dev, B, D, H, W, C):
+        """The channels-last cost-volume buffer of this module for one shape on one device."""
+        key = ("cv", dev)
+        cv = self._ws.get(key)
+        if cv is None or tuple(cv.shape) != (B, D, H, W, C):
+            cv = torch.empty((B, D, H, W, C), dtype=torch.float32, device=dev)
+            self._ws[key] = cv
+        return cv
+
+    def stage0(self, left_feature_map, right_feature_map, max_disp, return_reg=False):
+        """SparseDenseNetRefinementMask.forward :127-137 in one call: cost volume (stage-0 ``arange``
+        samples) -> this regulariser -> soft-argmax.  [B,C,H,W] x2 -> pred [B,H,W] (, reg [B,D,H,W])."""
+        left = left_feature_map.contiguous()
+        right = right_feature_map.contiguous()
+        if left.shape[1] % 4:                           # see prepare()
+            padc = (0, 0, 0, 0, 0, 4 - left.shape[1] % 4)
+            left = torch.nn.functional.pad(left, padc)
+            right = torch.nn.functional.pad(right, padc)
+        B, C, H, W = left.shape
+        D = int(max_disp)
+        cv = self.costvol_buffer(left.device, B, D, H, W, C)
+        costvol_ndhwc(left, right, D, out=cv)
+        reg, pred = self.run_ndhwc(cv, want_reg=return_reg, want_pred=True)
+        return (pred, reg) if return_reg else pred
+
 
 def disparity_regression(cost_vol, disp_samples):
     """submodule.py:766-777: softmax over dim 1, expectation of disp_samples.  N*S*H*W -> N*H*W"""
@@ -333,27 +366,12 @@ def disparity_regression(cost_vol, disp_samples):
 class Stage0(nn.Module):
     """The whole stage-0 branch of SparseDenseNetRefinementMask.forward (:127-137) as one
     call: get_disp_samples -> GetCostVolume -> CostRegNetNoDown -> disparity_regression,
-    with no [B,C,D,H,W] tensor ever leaving the channels-last workspace."""
+    with no [B,C,D,H,W] tensor ever leaving the channels-last workspace.  A thin wrapper of
+    ``CostRegNetNoDown.stage0`` (all caches live on the regulariser, keyed by device)."""
 
     def __init__(self, cost_regularizer):
         super(Stage0, self).__init__()
         self.cost_regularizer = cost_regularizer
-        self._cv = {}
 
     def forward(self, left_feature_map, right_feature_map, max_disp, return_reg=False):
-        left = left_feature_map.contiguous()
-        right = right_feature_map.contiguous()
-        if left.shape[1] % 4:                           # see CostRegNetNoDown.prepare
-            padc = (0, 0, 0, 0, 0, 4 - left.shape[1] % 4)
-            left = torch.nn.functional.pad(left, padc)
-            right = torch.nn.functional.pad(right, padc)
-        B, C, H, W = left.shape
-        D = int(max_disp)
-        key = (left.device, B, D, H, W, C)
-        cv = self._cv.get(key)
-        if cv is None:
-            cv = torch.empty((B, D, H, W, C), dtype=torch.float32, device=left.device)
-            self._cv = {key: cv}
-        costvol_ndhwc(left, right, D, out=cv)
-        reg, pred = self.cost_regularizer.run_ndhwc(cv, want_reg=return_reg, want_pred=True)
-        return (pred, reg) if return_reg else pred
+        return self.cost_regularizer.stage0(left_feature_map, right_feature_map, max_disp, return_reg)
