@@ -14,8 +14,9 @@ max_disp 192 -> 216 as the reference rounds it, demo.py:153):
               DataParallel gather, eval.py:146) -- pairs are sharded, weak scaling; the gather
               of step k overlaps step k+1.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without WORLD_SIZE: starts N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config 5 --gpus 4                   (training share: SpaMat fwd+bwd + gradient all-reduce)
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
 """
@@ -39,7 +40,10 @@ CONFIGS = {
     2: ("config 2: synthetic 960x540 (padded 972x540), max_disp 192->216", 540, 972, 216, 8),
     3: ("config 3: KITTI 1242x375 (padded 1242x378), max_disp 192->216, batch 32 over 8 GPUs", 378, 1242, 216, 4),
     4: ("config 4: Middlebury half-res 1500x1000 (padded 1512x1026), max_disp 256->270", 1026, 1512, 270, 1),
+    5: ("config 5: Sceneflow training step share (SpaMat forward+backward, stages 1-3), 972x540, max_disp 216, "
+        "batch 16 over 4 GPUs", 540, 972, 216, 4),
 }
+N_PARAMS = 13_190_000        # parameters of the shipped base_channels=8 network: 52.7 MB of fp32 gradients
 CONFIG_NAME, PAD_H, PAD_W, MAX_DISP, DEFAULT_B = CONFIGS[2]
 
 
@@ -316,6 +320,168 @@ def train_leg(dev, B=4, iters=30):
             "by_density": res}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) under
+    torch.distributed.run and pass their output through; rank 0 prints the JSON line.  This parent has not
+    touched the GPU (no HIP call before this point) and it does not exec: the ranks are child processes."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_cpu(args, world, rank):
+    """--selftest-cpu: the N-rank plumbing (rendezvous, pair sharding, the disparity all-gather, the bucketed
+    gradient all-reduce) on the gloo backend without a GPU.  No kernel runs and nothing is measured: `value`
+    is null.  Used by tests/test_bench_cpu.py to cover the self-launch path in the build container."""
+    from decnet_amd import dist as dd
+    torch.distributed.init_process_group("gloo")
+    assert torch.distributed.get_world_size() == args.gpus, "rendezvous has %d ranks, --gpus %d" % (
+        torch.distributed.get_world_size(), args.gpus)
+    B = args.pairs_per_gpu or 2
+    s, e = dd.shard_range(world * B, rank, world)
+    local = torch.arange(s, e, dtype=torch.float32).view(-1, 1, 1).expand(-1, 4, 6).contiguous()
+    got = dd.gather_disparity(local, n_pairs=world * B)
+    ok = bool(torch.equal(got[:, 0, 0], torch.arange(world * B, dtype=torch.float32)))
+    gb = dd.GradBuckets(4096, n_buckets=4)
+    for i in range(len(gb)):
+        gb.bucket(i).fill_(float(rank))
+        gb.reduce_async(i)
+    gb.wait()
+    ok = ok and bool(torch.allclose(gb.flat, torch.full_like(gb.flat, (world - 1) / 2.0)))
+    t = torch.tensor([1.0 if ok else 0.0])
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest (no GPU work)", "value": None, "unit": "pairs/s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "selftest": True, "ok": bool(t.item() == 1.0),
+                          "backend": "gloo"}), flush=True)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    return 0 if t.item() == 1.0 else 1
+
+
+class TrainShare:
+    """BASELINE config 5, the hot path's share of one data-parallel training step on this rank's pairs:
+    SpaMat forward (sparse_matching_forward) and backward (ref + tar gradients) at stages 1-3 through the C ABI
+    on preallocated buffers, and the all-reduce of the network's 52.7 MB of parameter gradients in 4 buckets,
+    each launched right after one of the backward stages so that RCCL moves it while the next stage's kernels
+    run (the gradients in the buffer are synthetic: the 2-D trunk's backward is PyTorch's, outside this path)."""
+
+    def __init__(self, B, dev, density, world):
+        from decnet_amd import dist as dd, ops
+        self.ops, self.B, self.world = ops, B, world
+        self.feats, self.masks = make_inputs(B, dev, density, seed=555 + 1000 * int(os.environ.get("RANK", 0)))
+        self.buf = {}
+        for s in (1, 2, 3):
+            C, H, W, D = STAGES[s]
+            g = torch.Generator(device=dev).manual_seed(9 + s)
+            self.buf[s] = dict(go=torch.randn(B, H, W, device=dev, generator=g),
+                               o=torch.empty(B, H, W, device=dev), ss=torch.empty(B, H, W, device=dev),
+                               mc=torch.empty(B, H, W, device=dev), gl=torch.empty(B, C, H, W, device=dev),
+                               gr=torch.empty(B, C, H, W, device=dev))
+        self.grads = dd.GradBuckets(N_PARAMS, n_buckets=4, device=dev)
+        self.grads.flat.normal_(generator=torch.Generator(device=dev).manual_seed(3))
+
+    def step(self):
+        ops = self.ops
+        for s in (1, 2, 3):
+            (L, R), (rm, tm), b = self.feats[s], self.masks[s], self.buf[s]
+            ops.spamat_forward(L, R, rm, tm, b["o"], b["ss"], b["mc"], STAGES[s][3])
+        nb = len(self.grads)
+        for k, s in enumerate((3, 2, 1)):             # backward runs fine-to-coarse
+            (L, R), (rm, tm), b = self.feats[s], self.masks[s], self.buf[s]
+            ops.spamat_backward(L, R, rm, tm, b["o"], b["ss"], b["mc"], b["go"], b["gl"], b["gr"], STAGES[s][3])
+            if self.world > 1:
+                for i in ([0], [1], list(range(2, nb)))[k]:
+                    self.grads.reduce_async(i)
+        if self.world > 1:
+            self.grads.wait()
+
+    def drain(self):
+        pass
+
+
+def timed_region(step, drain, warmup, steps, world, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    drain()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def main_train(args, B, dev, world, rank):
+    """--config 5 (see TrainShare)."""
+    ts = TrainShare(B, dev, args.mask_density, world)
+    with torch.no_grad():
+        elapsed = timed_region(ts.step, ts.drain, args.warmup, args.steps, world, dev)
+        if rank == 0:
+            ms_step = 1e3 * elapsed / args.steps
+            C, H, W, D = STAGES[3]
+            (L, R), (rm, tm), b = ts.feats[3], ts.masks[3], ts.buf[3]
+            tb = time_kernel(lambda: ts.ops.spamat_backward(L, R, rm, tm, b["o"], b["ss"], b["mc"], b["go"], b["gl"],
+                                                            b["gr"], D), 30)
+            tf = time_kernel(lambda: ts.ops.spamat_forward(L, R, rm, tm, b["o"], b["ss"], b["mc"], D), 30)
+            nb = 4.0 * B * H * W * (4 * C + 6)
+            t_ar = None
+            if world > 1:                                # the gradient all-reduce alone, not overlapped
+                def ar():
+                    for i in range(len(ts.grads)):
+                        ts.grads.reduce_async(i)
+                    ts.grads.wait()
+                t_ar = time_kernel(ar, 10, warm=3)
+            traffic = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    traffic = json.load(f)
+            except (OSError, ValueError):
+                pass
+            out = {
+                "metric": "stereo pairs/sec, BASELINE config 5 share (SpaMat forward+backward, stages 1-3, + "
+                          "all-reduce of 52.7 MB of gradients)",
+                "value": world * B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE %s: %d pairs per GPU, feature maps of the 4-stage/scale-3 net; the "
+                                       "gradient buffer is synthetic (the 2-D trunk's backward is outside the path)"
+                                       % (CONFIG_NAME, B),
+                           "pairs_per_gpu": B, "mask_density": args.mask_density, "grad_bytes": 4 * N_PARAMS,
+                           "grad_buckets": len(ts.grads),
+                           "parallelism": "dp%d (pairs sharded, bucketed all_reduce of gradients)" % world},
+                "roofline": {"bound": "hbm", "achieved": nb / tb / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": nb / tb / 1e6 / HBM_PEAK_GBS,
+                             "traffic": traffic.get("spamat_bwd_stage3", {}).get("total_bytes"),
+                             "kernel": "spamat backward (ref + tar gradient launches), stage 3", "ms": tb,
+                             "bytes_per_launch": nb, "fwd_ms": tf},
+                "allreduce_alone_ms": t_ar,
+            }
+            print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,7 +489,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
                     help="BASELINE.json config (2 = the metric's; 3, 4: the other single-GPU-shard shapes)")
-    ap.add_argument("--pairs-per-gpu", type=int, default=0, help="default: the config's (8 / 4 / 1)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0, help="default: the config's (8 / 4 / 1 / 4)")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="no GPU: exercise the N-rank launch, sharding and collectives on gloo (value null)")
     ap.add_argument("--mask-density", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-density-sweep", action="store_true",
@@ -341,11 +509,16 @@ def main():
                          "trunk around the hot path) timed on the same batch, eager and as a HIP-graph replay")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: one process per GPU, started here, before anything touches HIP
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.selftest_cpu:
+        raise SystemExit(selftest_cpu(args, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local)
@@ -353,9 +526,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
+        if torch.distributed.get_world_size() != args.gpus:
+            raise SystemExit("RCCL sees %d ranks, --gpus %d" % (torch.distributed.get_world_size(), args.gpus))
 
     set_config(args.config)
     B = args.pairs_per_gpu or DEFAULT_B
+    if args.config == 5:
+        return main_train(args, B, dev, world, rank)
     hp = HotPath(B, dev, args.mask_density, world)
     hp.overlap = not args.no_overlap
 
@@ -365,16 +542,8 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            hp.step()
-        hp.drain()
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            hp.step()                                   # nothing but the work: no events inside the timed region
-        hp.drain()                                      # every all-gather has landed inside the timed region
-        barrier()
-        elapsed = time.perf_counter() - t0
+        # nothing but the work inside the timed region (no events); every all-gather has landed when it ends
+        elapsed = timed_region(hp.step, hp.drain, args.warmup, args.steps, world, dev)
         # per-stage breakdown from a few extra steps with events around stage 0 and stage 3 (an event
         # record costs ~20 us of pipeline bubble each, so they stay out of the timed region)
         nev = min(args.steps, 10)
@@ -384,11 +553,6 @@ def main():
             hp.step(ev[i])
         hp.drain()
         barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     if rank == 0:
         # HBM-side traffic per launch comes from a separate rocprofv3 --pmc pass (counters cannot be
         # read from inside the process); profiles/traffic.json records the command and corrections.

@@ -75,3 +75,54 @@ def gather_disparity(local, n_pairs=None, group=None, out=None, async_op=False):
         return (out, work) if async_op else out
     res = torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], 0)
     return (res, None) if async_op else res
+
+
+class GradBuckets:
+    """Bucketed gradient all-reduce for the data-parallel training configuration (BASELINE config 5;
+    the reference's analogue is DataParallel's reduce of replica gradients onto GPU 0, eval.py:145-146 /
+    sync_batchnorm/batchnorm.py:110-131 for the BN statistics).
+
+    One flat fp32 buffer of ``numel`` gradients (13.19 M parameters = 52.7 MB for the shipped network)
+    is cut into ``n_buckets`` contiguous buckets.  ``reduce_async(i)`` enqueues the all-reduce of bucket i
+    behind whatever the current stream holds at that moment and returns at once -- RCCL runs it on its own
+    stream, so it overlaps the backward kernels enqueued afterwards (xGMI ring: 2(N-1)/N x bucket bytes per
+    link, ~13 MB buckets keep each collective in the bandwidth regime without delaying the first one).
+    ``wait()`` makes the current stream wait for all of them and turns the sums into means.
+    """
+
+    def __init__(self, numel, n_buckets=4, device="cpu", group=None, dtype=torch.float32):
+        if n_buckets < 1 or numel < n_buckets:
+            raise ValueError("need 1 <= n_buckets <= numel")
+        self.group = group
+        self.flat = torch.zeros(int(numel), dtype=dtype, device=device)
+        per = (int(numel) + n_buckets - 1) // n_buckets
+        per = (per + 63) // 64 * 64                         # 256-byte aligned bucket starts
+        self.bounds = [(i * per, min(int(numel), (i + 1) * per)) for i in range(n_buckets)
+                       if i * per < int(numel)]
+        self.pending = {}
+
+    def __len__(self):
+        return len(self.bounds)
+
+    def bucket(self, i):
+        s, e = self.bounds[i]
+        return self.flat[s:e]
+
+    def reduce_async(self, i):
+        if i in self.pending:
+            raise RuntimeError("bucket %d is already being reduced" % i)
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            self.pending[i] = None
+            return
+        self.pending[i] = dist.all_reduce(self.bucket(i), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self):
+        """Wait for every bucket in flight; gradients become the mean over ranks."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        for i in sorted(self.pending):
+            w = self.pending[i]
+            if w is not None:
+                w.wait()
+            if world > 1:
+                self.bucket(i).mul_(1.0 / world)
+        self.pending = {}

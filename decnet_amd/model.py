@@ -538,10 +538,20 @@ def get_model(**params):
     return SparseDenseNetRefinementMask(**{k: params[k] for k in keys})
 
 
-def load_reference_checkpoint(model, state):
-    """demo.py:124-133: strip DataParallel's ``module.`` prefix, keep the model's own values for keys
-    the checkpoint lacks (the reference also carries parameter-free loss modules)."""
+def load_reference_checkpoint(model, state, strict=True):
+    """demo.py:124-133: strip DataParallel's ``module.`` prefix and load.  The reference merges the checkpoint
+    into the model's own state_dict, so a checkpoint with foreign key names silently loads nothing and the net
+    runs on its random init; here (``strict=True``) every parameter and BatchNorm statistic of the model must
+    come from the checkpoint and every checkpoint key must be consumed, else RuntimeError names the keys.
+    Allowed: a missing ``num_batches_tracked`` (checkpoints of older PyTorch), and keys of the reference's
+    parameter-free loss modules (``train_loss_func.*``, ``test_mask_loss_func.*``)."""
     own = model.state_dict()
-    own.update({k.replace("module.", ""): v for k, v in state.items() if k.replace("module.", "") in own})
+    ckpt = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+    missing = [k for k in own if k not in ckpt and not k.endswith("num_batches_tracked")]
+    extra = [k for k in ckpt if k not in own and not k.startswith(("train_loss_func.", "test_mask_loss_func."))]
+    if strict and (missing or extra):
+        raise RuntimeError("checkpoint does not match the network: %d model keys missing (e.g. %s), %d checkpoint "
+                           "keys unused (e.g. %s)" % (len(missing), missing[:3], len(extra), extra[:3]))
+    own.update({k: v for k, v in ckpt.items() if k in own})
     model.load_state_dict(own)
     return model

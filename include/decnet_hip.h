@@ -16,6 +16,11 @@
  *   - Outputs are fully written by the callee (entries the reference leaves to the
  *     caller's zero fill, functions/SpaMat.py:25-27,42-43, are written as 0), so the
  *     caller does not have to clear them.  Inputs are never modified.
+ *   - Inputs must be finite.  The reference propagates a NaN feature into every output it
+ *     touches (fmaxf/expf on NaN, SM_kernel.cu:46-58); the SpaMat/SpaVar forward kernels here
+ *     are built with -fno-honor-nans (decnet_amd/build.py), so a NaN input gives an unspecified
+ *     value at the pixels whose candidate set contains it -- never a fault, never an effect on
+ *     other pixels.  Check inputs upstream (torch.isfinite) when that matters.
  *   - Return value: 0 (DECNET_OK) on success, a negative DECNET_ERR_* for rejected
  *     arguments (nothing is enqueued), or a positive hipError_t from the launch.
  *     (The reference's pybind functions always return 1 and check nothing,

@@ -1,0 +1,33 @@
+"""bench.py's multi-rank launch path, on CPU: `python bench.py --gpus N` without a launcher must start N
+ranks itself (one per GPU) and rank 0 must print ONE line with n_gpus == N; a WORLD_SIZE that disagrees with
+--gpus is an error, never a silent single-rank run.  --selftest-cpu swaps
+RCCL for gloo and runs the sharding / all-gather / bucketed all-reduce plumbing only (no kernels, value null)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra, *flags):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
+                          timeout=300, cwd=ROOT, env=env)
+
+
+def test_gpus_2_starts_two_ranks_itself():
+    r = _run({}, "--gpus", "2", "--selftest-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ok"] is True and d["value"] is None and d["selftest"] is True
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--selftest-cpu")
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

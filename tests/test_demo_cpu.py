@@ -1,8 +1,13 @@
 """Host-side pre/post-processing of the demo counterpart (demo.py:75-98, 149-155, 191-197). CPU."""
+import os
+import sys
+
 import numpy as np
 import torch
 
 from decnet_amd import demo
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 
 
 def test_padding_is_top_left_to_multiple_of_27():
@@ -61,3 +66,27 @@ def test_host_detail_masks():
     # sizes that are not multiples of 27 get the reference's top/left padding, whose mask part is cleared
     ms = detail_detection(np.random.default_rng(1).random((50, 70, 3)).astype(np.float32))
     assert ms[0].shape == (54, 81) and not ms[0][:4].any() and not ms[0][:, :11].any()
+
+
+def test_checkpoint_loader_is_strict():
+    """demo.py:124-133 merges whatever matches; a checkpoint with foreign key names would silently leave the
+    net on its random init.  Here that is an error, and DataParallel's prefix is stripped."""
+    import pytest
+    from make_golden import E2E_KW
+    from decnet_amd.model import get_model, load_reference_checkpoint
+    torch.manual_seed(0)
+    a, b = get_model(**E2E_KW), get_model(**E2E_KW)
+    sd = a.state_dict()
+    load_reference_checkpoint(b, {"module." + k: v for k, v in sd.items()})
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in sd.items())
+    # tolerated: no num_batches_tracked (old PyTorch), the reference's loss-module keys
+    ok = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    ok["train_loss_func.dummy"] = torch.zeros(1)
+    load_reference_checkpoint(b, ok)
+    with pytest.raises(RuntimeError, match="missing"):
+        load_reference_checkpoint(b, {"model." + k: v for k, v in sd.items()})      # foreign prefix: nothing matches
+    part = dict(sd)
+    del part["cost_regularizer.conv0.0.conv.weight"]
+    with pytest.raises(RuntimeError, match="cost_regularizer.conv0.0.conv.weight"):
+        load_reference_checkpoint(b, part)
+    load_reference_checkpoint(b, part, strict=False)                                # the reference's behaviour

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from decnet_amd.dist import gather_disparity, shard_batch, shard_range
+from decnet_amd.dist import GradBuckets, gather_disparity, shard_batch, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -60,6 +60,18 @@ def _worker(rank, world, n_pairs, port, ret):
         else:                                       # uneven shards: async falls back to a finished gather
             g3, w3 = gather_disparity(pred, n_pairs=n_pairs, async_op=True)
             assert w3 is None and torch.equal(g3, full * 2 + 1)
+        # config 5: bucketed gradient all-reduce, buckets launched one by one between "backward kernels"
+        gb = GradBuckets(1000, n_buckets=3)
+        assert len(gb) == 3 and gb.bounds[0][0] == 0 and gb.bounds[-1][1] == 1000
+        assert all(a[1] == b[0] for a, b in zip(gb.bounds, gb.bounds[1:]))
+        for step in range(2):
+            for i in range(len(gb)):
+                gb.bucket(i).fill_(float(rank + 1 + i + step))      # this rank's gradients of bucket i
+                gb.reduce_async(i)
+            gb.wait()
+            for i in range(len(gb)):
+                want = sum(r + 1 + i + step for r in range(world)) / world
+                assert torch.allclose(gb.bucket(i), torch.full_like(gb.bucket(i), want)), (i, step)
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

@@ -10,16 +10,20 @@
 set -e
 cd "$(dirname "$0")/.."
 S=decnet_amd/csrc
-COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared"
-for a in 1 2 3 4 5; do
-  hipcc $COMMON -fno-honor-nans -DDECNET_ABLATE=$a $S/spamat_mfma.hip $S/spamat_bwd_mfma.hip $S/capi.hip \
-        $S/spamat_rowtile.hip $S/stage0.hip $S/conv3d_winograd.hip -o tools/ubench/libdecnet_abl$a.so
-done
-for a in 1 2 3 4 5 6; do
-  hipcc $COMMON -DDECNET_CONV_ABLATE=$a $S/stage0.hip $S/capi.hip $S/spamat_rowtile.hip \
-        $S/spamat_bwd_mfma.hip -fno-honor-nans $S/spamat_mfma.hip $S/conv3d_winograd.hip -o tools/ubench/libdecnet_cabl$a.so
-done
-for a in 1 2 3 5; do
-  hipcc $COMMON -DDECNET_WINO_ABLATE=$a $S/conv3d_winograd.hip $S/stage0.hip $S/capi.hip $S/spamat_rowtile.hip \
-        $S/spamat_bwd_mfma.hip -fno-honor-nans $S/spamat_mfma.hip -o tools/ubench/libdecnet_wabl$a.so
-done
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
+# every .hip of the library goes into each ablation build (the ctypes loader binds every symbol of
+# include/decnet_hip.h); -fno-honor-nans only for spamat_mfma.hip, as decnet_amd/build.py does
+build() {   # build <define> <output>
+  local objs=() tmp; tmp=$(mktemp -d)
+  for f in $S/*.hip; do
+    local extra=""; [ "$(basename $f)" = spamat_mfma.hip ] && extra="-fno-honor-nans"
+    hipcc $COMMON $extra $1 -c $f -o $tmp/$(basename $f).o &
+    objs+=($tmp/$(basename $f).o)
+  done
+  wait
+  hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $2
+  rm -rf $tmp
+}
+for a in 1 2 3 4 5; do build -DDECNET_ABLATE=$a tools/ubench/libdecnet_abl$a.so; done
+for a in 1 2 3 4 5 6; do build -DDECNET_CONV_ABLATE=$a tools/ubench/libdecnet_cabl$a.so; done
+for a in 1 2 3 5; do build -DDECNET_WINO_ABLATE=$a tools/ubench/libdecnet_wabl$a.so; done
