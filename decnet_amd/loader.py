@@ -1,0 +1,148 @@
+"""Evaluation-time data sources for decnet_amd.eval.
+
+Two layouts, both yielding the tuple the reference's datasets return in test mode
+(loader/SceneflowMask.py:198-203): ``left, right, disparity, image, left_mask1..3, right_mask1..3,
+ori_h, ori_w, name, n_disp`` with the images padded on the top/left to multiples of 27
+(SceneflowMask.py:118-130), scaled to [0,1] and normalised with the ImageNet statistics (:152-153,
+:206-210):
+
+* ``NpyPairs``  -- the reference's pre-baked format: ``<root>/<split>/*.npy`` arrays ``[H,W,7]`` (left RGB,
+  right RGB, disparity; SceneflowMask.py:115,144-146) and, optionally, the pickled list of six detail masks
+  next to them in ``<root>/<split>_mask/<name>`` (left fine->coarse, right fine->coarse; :166-185).
+* ``PairDirectory`` -- demo.py's layout: ``<root>/<name>/im0.png, im1.png [, calib.txt] [, disp0.pfm |
+  disp0.png (uint16, x256)]``.
+
+Without stored masks the three per-view detail masks come from decnet_amd.masks.detail_detection (the
+reference bakes the same function's output into the pickles); with ``use_detail`` the network ignores them
+(SparseDenseNetRefinementMask.py:148-170) and ones are returned.  Training-time augmentation
+(random crops, add_paralex_noise) is not part of the inference hot path and is not reproduced.
+"""
+import math
+import os
+import pickle
+import re
+
+import numpy as np
+import torch
+from torch.utils import data
+
+MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+STD = np.array([0.229, 0.224, 0.225], np.float32)
+
+
+def pad_top_left(arr, multiple=27):
+    """Zero pad [H,W,C] on the TOP and LEFT up to the next multiple (demo.py:75-81, SceneflowMask.py:118-128)."""
+    h, w = arr.shape[:2]
+    rh = int(math.ceil(h / multiple) * multiple) - h
+    rw = int(math.ceil(w / multiple) * multiple) - w
+    out = np.zeros((h + rh, w + rw) + arr.shape[2:], dtype=np.float32)
+    out[rh:, rw:] = arr
+    return out
+
+
+def normalise(img01):
+    x = (img01.astype(np.float32) - MEAN) / STD
+    return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))).float()
+
+
+def read_pfm(path):
+    """utils/utils.py:281-321: 'Pf' / 'PF' header, dims, scale (negative = little endian), rows bottom-up."""
+    with open(path, "rb") as f:
+        header = f.readline().rstrip().decode("utf-8")
+        if header not in ("PF", "Pf"):
+            raise Exception("Not a PFM file.")
+        m = re.match(r"^(\d+)\s(\d+)\s$", f.readline().decode("utf-8"))
+        if not m:
+            raise Exception("Malformed PFM header.")
+        width, height = map(int, m.groups())
+        scale = float(f.readline().rstrip().decode("utf-8"))
+        endian = "<" if scale < 0 else ">"
+        d = np.frombuffer(f.read(), endian + "f4")
+    shape = (height, width, 3) if header == "PF" else (height, width)
+    return np.flipud(d.reshape(shape)).astype(np.float32), abs(scale)
+
+
+def _masks(img01_padded, stored, use_detail):
+    """Three masks of one view, coarsest first (stage 1..3), float [h,w]."""
+    if stored is not None:                              # fine -> coarse in the pickle (SceneflowMask.py:177-184)
+        return [torch.from_numpy(np.asarray(m)).float() for m in stored[::-1]]
+    H, W = img01_padded.shape[:2]
+    if use_detail:                                      # placeholders: the network makes its own masks
+        return [torch.ones(H // s, W // s) for s in (9, 3, 1)]
+    from .masks import detail_detection
+    return [torch.from_numpy(m.astype(np.float32)) for m in detail_detection(img01_padded)[::-1]]
+
+
+class _Base(data.Dataset):
+    def __init__(self, use_detail=True, max_disp=192):
+        self.use_detail, self.n_disp = use_detail, max_disp
+
+    def _item(self, left_u8, right_u8, disp, name, n_disp, lmasks=None, rmasks=None):
+        ori_h, ori_w = left_u8.shape[:2]
+        lp, rp = pad_top_left(left_u8.astype(np.float32)) / 255, pad_top_left(right_u8.astype(np.float32)) / 255
+        gt = torch.from_numpy(pad_top_left(disp.astype(np.float32)))
+        lm, rm = _masks(lp, lmasks, self.use_detail), _masks(rp, rmasks, self.use_detail)
+        image = torch.from_numpy(np.ascontiguousarray(pad_top_left(left_u8.astype(np.float32)).transpose(2, 0, 1)))
+        return (normalise(lp), normalise(rp), gt, image, lm[0], lm[1], lm[2], rm[0], rm[1], rm[2], ori_h, ori_w,
+                name, n_disp)
+
+
+class NpyPairs(_Base):
+    def __init__(self, root, split="test", **kw):
+        super().__init__(**kw)
+        p = os.path.join(root, split)
+        if os.path.isfile(p):
+            self.paths = sorted(str(s) for s in np.load(p))
+        else:
+            self.paths = sorted(os.path.join(p, f) for f in os.listdir(p) if f.endswith(".npy"))
+        if not self.paths:
+            raise Exception("No files under/in {}/{}".format(root, split))
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        path = self.paths[i]
+        arr = np.load(path)
+        name = os.path.basename(path).split(".")[0]
+        d = os.path.dirname(path)
+        mpath = os.path.join(d + "_mask", name)
+        lm = rm = None
+        if os.path.exists(mpath):
+            with open(mpath, "rb") as f:
+                m = pickle.load(f)
+            lm, rm = m[0:3], m[3:6]
+        return self._item(arr[..., 0:3], arr[..., 3:6], arr[..., 6], name, self.n_disp, lm, rm)
+
+
+class PairDirectory(_Base):
+    def __init__(self, root, **kw):
+        super().__init__(**kw)
+        self.root = root
+        self.names = sorted(n for n in os.listdir(root) if os.path.isfile(os.path.join(root, n, "im0.png")))
+        if not self.names:
+            raise Exception("No pairs under {}".format(root))
+
+    def __len__(self):
+        return len(self.names)
+
+    def __getitem__(self, i):
+        from .demo import read_ndisp, read_rgb
+        d = os.path.join(self.root, self.names[i])
+        left, right = read_rgb(os.path.join(d, "im0.png")), read_rgb(os.path.join(d, "im1.png"))
+        if os.path.exists(os.path.join(d, "disp0.pfm")):
+            disp = read_pfm(os.path.join(d, "disp0.pfm"))[0]
+            disp = np.where(np.isfinite(disp), disp, 0).astype(np.float32)
+        elif os.path.exists(os.path.join(d, "disp0.png")):
+            from PIL import Image
+            disp = np.asarray(Image.open(os.path.join(d, "disp0.png"))).astype(np.float32) / 256
+        else:
+            disp = np.zeros(left.shape[:2], np.float32)
+        n = read_ndisp(os.path.join(d, "calib.txt"))
+        return self._item(left, right, disp, self.names[i], n if n > 0 else self.n_disp)
+
+
+def get_loader(name):
+    """loader/__init__.py:8-21 (the four reference datasets share the pre-baked .npy layout) + 'pairs'."""
+    return {"kitti15mask": NpyPairs, "sceneflowmask": NpyPairs, "drivingstereomask": NpyPairs,
+            "middleburymask": NpyPairs, "pairs": PairDirectory}[name.lower()]
