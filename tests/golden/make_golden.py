@@ -40,12 +40,14 @@ class _ExtStub:
 
     @staticmethod
     def sparse_matching_cuda_forward(ref, tar, rm, tm, out, ssum, mx, max_disp):
+        ref, tar, rm, tm = (t.float() for t in (ref, tar, rm, tm))       # (a .double() graph: see fp32_noise)
         o, s, m = oracle.spamat_forward(ref, tar, rm, tm, max_disp)
         out.copy_(torch.from_numpy(o)); ssum.copy_(torch.from_numpy(s)); mx.copy_(torch.from_numpy(m))
         return 1
 
     @staticmethod
     def sparse_var_cuda_forward(ref, tar, rm, tm, disp, out, ssum, mx, max_disp):
+        ref, tar, rm, tm, disp = (t.float() for t in (ref, tar, rm, tm, disp))
         o, s, m = oracle.spavar_forward(ref, tar, rm, tm, disp, max_disp)
         out.copy_(torch.from_numpy(o)); ssum.copy_(torch.from_numpy(s)); mx.copy_(torch.from_numpy(m))
         return 1
