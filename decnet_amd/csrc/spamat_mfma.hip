@@ -150,6 +150,63 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
     float mx = fmaxf(mx0, mx1);
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (!COMPACT && MODE != MODE_MAT) {
+        // ---- dense rows, variance wanted: passes 2 + 3 through per-tile moments.  A lane's four values of
+        // tile m sit at d = A - r, A = 16 m + dl, r = 0..3.  Pass 2 keeps s = sum e_r, t2 = 2 sum r e_r,
+        // q = sum r^2 e_r per tile (3 registers instead of the 4 exponentials); then
+        //   S = sum s,   T = sum (16 m) s - sum t2 / 2 + dl S,   V = sum_m (A - mu) ((A - mu) s - t2) + q
+        // -- 3.5 VALU operations per candidate instead of 5, and no cancellation: the expansion is around
+        // the tile's own position, every term is of the size of e (d - mu)^2 itself.
+        // (measured in tools/ubench/softmax_rate.hip: 2440 vs 2900 cycles per 60 candidates per SIMD)
+        const float nmv = -mx * LOG2E;
+        float Sa = 0.f, Sb = 0.f, T16a = 0.f, T16b = 0.f, Tt = 0.f;
+#pragma unroll
+        for (int m = 0; m < NTL; ++m) {
+            if (m < ntile) {
+                const float e0 = fast_exp2(fmaf(acc[m][0], LOG2E, nmv));
+                const float e1 = fast_exp2(fmaf(acc[m][1], LOG2E, nmv));
+                const float e2 = fast_exp2(fmaf(acc[m][2], LOG2E, nmv));
+                const float e3 = fast_exp2(fmaf(acc[m][3], LOG2E, nmv));
+                const float s4 = (e0 + e1) + (e2 + e3);
+                const float t2 = fmaf(6.f, e3, fmaf(4.f, e2, e1 + e1));
+                const float qq = fmaf(9.f, e3, fmaf(4.f, e2, e1));
+                acc[m][0] = s4;
+                acc[m][1] = t2;
+                acc[m][2] = qq;
+                if (m & 1) { Sb += s4; T16b = fmaf(s4, (float)(16 * m), T16b); }
+                else { Sa += s4; T16a = fmaf(s4, (float)(16 * m), T16a); }
+                Tt += t2;
+            }
+        }
+        const float dlf = (float)dl;
+        float Sl = Sa + Sb;
+        float Tl = fmaf(dlf, Sl, fmaf(-0.5f, Tt, T16a + T16b));
+        Sl += __shfl_xor(Sl, 16);
+        Sl += __shfl_xor(Sl, 32);
+        const float S = Sl + 0.000001f;
+        float mu = mu_in;
+        if (MODE != MODE_VAR) {
+            Tl += __shfl_xor(Tl, 16);
+            Tl += __shfl_xor(Tl, 32);
+            mu = (Tl + 0.000001f) / S;
+        }
+        const float c0 = dlf - mu;
+        float V0 = 0.f, V1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < NTL; ++m) {
+            if (m < ntile) {
+                const float A = (float)(16 * m) + c0;
+                const float u = fmaf(A, acc[m][0], -acc[m][1]);
+                if (m & 1) V1 = fmaf(A, u, V1) + acc[m][2];
+                else V0 = fmaf(A, u, V0) + acc[m][2];
+            }
+        }
+        float Vl = V0 + V1;
+        Vl += __shfl_xor(Vl, 16);
+        Vl += __shfl_xor(Vl, 32);
+        mx_o = mx; S_o = S; mu_o = mu; var_o = (Vl + 0.000001f) / S;
+        return;
+    }
     // ---- pass 2: e = exp(cost - max) (one fma: cost*log2e - max*log2e), S, T (SM_kernel.cu:100-122)
     const float nm = -mx * LOG2E;
     float S0 = 0.f, S1 = 0.f, T0 = 0.f, T1 = 0.f;
@@ -294,20 +351,29 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
         if (lane == 63) { WT[wave] = ir; WT[8 + wave] = il; }
     }
 
-    // ---------------- phase 2: stage R (every load of an 8-channel group before its stores) ------
+    // ---------------- phase 2: stage R.  Threads are spread over (channel row, group of 4 positions): a row
+    // of the staged window takes nRw/4 threads, the rest of the workgroup takes further channel rows, and
+    // every thread has up to 8 loads in flight before its stores (stage 1, C = 72 over 144 positions:
+    // 6 loads per thread instead of 72 serial ones on 36 threads).
     {
         const bool al = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
-        for (int j = tid * 4; j < nRw; j += THREADS * 4) {
-            const int x = xs - HALO + j;
-            for (int c0 = 0; c0 < lo.Cq; c0 += 8) {
+        const int nq = nRw >> 2;                             // 16-byte groups per channel row (<= THREADS)
+        const int rpp = THREADS / nq;                        // channel rows per pass
+        const int r0 = tid / nq, jq = tid - r0 * nq;
+        if (r0 < rpp) {
+            const int jj = 4 * jq, x = xs - HALO + jj;
+            for (int c0 = r0; c0 < lo.Cq; c0 += 8 * rpp) {
                 float4 v[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    v[c] = c0 + c < C ? load4(rrow + (size_t)(c0 + c) * plane, x, W, al)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * rpp;
+                    v[u] = c < C ? load4(rrow + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if (c0 + c < lo.Cq) *reinterpret_cast<float4 *>(Rs + (c0 + c) * RP + j) = v[c];
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * rpp;
+                    if (c < lo.Cq) *reinterpret_cast<float4 *>(Rs + c * RP + jj) = v[u];
+                }
             }
         }
         for (int c = tid; c < lo.Cq; c += THREADS) Rs[c * RP + RP - 1] = 0.f;    // zero column
@@ -330,7 +396,7 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
     if (!compact) {
         // =========================== DENSE path ===========================================
         const int dl = j - 4 * q;                       // d = 16*m + dl - r
-        float bv[KB], bcur[KB];
+        float bv[KQ <= 6 ? KB : 1], bcur[KB];
         float rm = 0.f;
         auto fetch_left = [&](int xt, float (&dst)[KB]) {
             const int x = xs + xt * 16 + j;
@@ -341,7 +407,9 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
                     dst[s] = (ok && 4 * s + q < C) ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
             }
         };
-        fetch_left(wave, bv);
+        constexpr bool PREF = KQ <= 6;                  // next tile's left operand in flight (C = 72: no room, and
+                                                        // stage 1 has one tile per wave anyway)
+        if constexpr (PREF) fetch_left(wave, bv);
         for (int xt = wave; xt < XT; xt += NWAVE) {
             const int x0 = xs + xt * 16;
             if (x0 >= W) break;
@@ -349,9 +417,13 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
             const size_t pix = rowpix + x;
             const bool inside = x < W;
             rm = LM[xt * 16 + j];
+            if constexpr (PREF) {
 #pragma unroll
-            for (int s = 0; s < KB; ++s) bcur[s] = bv[s];
-            fetch_left(xt + NWAVE, bv);                 // prefetch the next tile's left operand
+                for (int s = 0; s < KB; ++s) bcur[s] = bv[s];
+                fetch_left(xt + NWAVE, bv);             // prefetch the next tile's left operand
+            } else {
+                fetch_left(xt, bcur);
+            }
             if (__ballot(rm != 0.f) == 0ull) {          // no active left pixel in this tile
                 if (inside && q == 0) {
                     if (MODE != MODE_VAR) out[pix] = 0.f;
@@ -781,8 +853,8 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     dim3 grid((unsigned)((size_t)B * H * segs)), block(THREADS);
     // sparse rows first (KQ > 0: C <= 24; rows of <= 2048 pixels), the rest by the marker launch
     static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
-    const int marker = allow_compact && !sparse_off && KQ > 0 && W <= 2048;
-    if (marker) {
+    const int marker = allow_compact && !sparse_off && KQ > 0 && KQ <= 6 && W <= 2048;
+    if constexpr (KQ > 0 && KQ <= 6) if (marker) {
         const int ppt = W <= 1024 ? 4 : 8;
         const size_t slds = 4 * (size_t)(SP_CAP + 16 + 2 * (SP_THREADS * ppt / 2 + 2) + SP_CAP + 16 +
                                          2 * 4 * KQ * SP_FP);
@@ -836,9 +908,14 @@ int launch_kq(int mode, const float *ref, const float *tar, const float *rmask, 
     return launch_nt<NT, K>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,        \
                             max_cost, B, C, H, W, D, allow_compact, stream)
     if (C <= 8 && C > 4) GO(2);        // stage 3 of the shipped network (C = 8)
+#ifdef DECNET_DEV_STAGE3               // tools/dev_spamat.sh: the stage-3 instantiation only (seconds to compile)
+    return DECNET_ERR_UNSUPPORTED;
+#else
     if (C <= 24 && C > 20) GO(6);      // stage 2 (C = 24)
-    GO(0);                             // anything else, incl. stage 1 (C = 72): runtime K loop,
-                                       // left operand read straight from L2/HBM per K-step
+    if (C <= 72 && C > 68) GO(18);     // stage 1 (C = 72)
+    GO(0);                             // anything else: runtime K loop, left operand read straight
+                                       // from L2/HBM per K-step
+#endif
 #undef GO
 }
 
@@ -856,6 +933,10 @@ int decnet_mfma_forward(int mode, const float *ref, const float *tar, const floa
 #define GO(N)                                                                                     \
     return launch_kq<N>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, \
                         B, C, H, W, D, allow_compact, stream)
+#ifdef DECNET_DEV_STAGE3
+    if (need <= 15 && need > 11) GO(15);
+    return DECNET_ERR_UNSUPPORTED;
+#endif
     if (need <= 3) GO(3);       // D <= 32   (stage 1: 24, 30)
     if (need <= 6) GO(6);       // D <= 80   (stage 2: 72)
     if (need <= 8) GO(8);       // D <= 112  (stage 2 at max_disp 270: 90)

@@ -36,7 +36,7 @@ def test_eval_and_submission_modes(tmp_path):
     assert np.abs(png.astype(np.int64) - want.astype(np.int64)).mean() < 1.0
     assert np.array_equal(png, np.asarray(Image.open(str(tmp_path / "out" / "b.png"))))
     # evaluation mode: ground truth = that output + 1 px where it is a valid disparity
-    gt = want.astype(np.float32) / 256 + 1.0
+    gt = np.where(want > 0, want.astype(np.float32) / 256 + 1.0, 0.0)       # clamped (negative) outputs: invalid
     for n in ("a", "b"):
         Image.fromarray(np.clip(gt * 256, 0, 65535).astype(np.uint16)).save(str(root / n / "disp0.png"))
     args = E.build_parser().parse_args(flags + ["--is_eval", "1"])
