@@ -49,9 +49,19 @@ SIGNATURES = {
     "decnet_conv3d_cout1_workspace_floats": [_I] * 4,
     "decnet_conv3d_cout1_softargmax_ws": [_P, _P, _F, _F, _P, _P, _P] + [_I] * 5 + [_P],
     "decnet_disparity_regression": [_P] * 3 + [_I] * 4 + [_P],
+    "decnet_stage0_workspace_floats": [_I] * 6,
+    "decnet_stage0_forward": [_P] * 6 + [_I] * 6 + [_P],
     "decnet_ncdhw_to_ndhwc": [_P, _P] + [_I] * 5 + [_P],
     "decnet_ndhwc_to_ncdhw": [_P, _P] + [_I] * 5 + [_P],
 }
+
+
+
+class Stage0Params(ctypes.Structure):
+    """decnet_stage0_params of include/decnet_hip.h (plain device pointers)."""
+    _fields_ = [("w", _P * 7), ("scale", _P * 7), ("shift", _P * 7), ("w_last", _P),
+                ("scale_last", _F), ("shift_last", _F)]
+
 
 ERRORS = {-1: "null pointer", -2: "bad shape", -3: "shape not supported by the gfx950 kernels"}
 

@@ -63,5 +63,19 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_ubench(force=False):
+    """tools/ubench/softmax_rate.bin: the VALU-floor microbenchmark bench.py runs beside the dense cost-volume
+    kernel (a stand-alone HIP program; a child process of bench.py, never linked into the library)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "ubench", "softmax_rate.hip")
+    out = os.path.join(root, "tools", "ubench", "softmax_rate.bin")
+    if not os.path.exists(src):
+        return None
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-O3", "-w", "-fno-honor-nans", src, "-o", out])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -333,19 +333,63 @@ class CostRegNetNoDown(nn.Module):
 
     def stage0(self, left_feature_map, right_feature_map, max_disp, return_reg=False):
         """SparseDenseNetRefinementMask.forward :127-137 in one call: cost volume (stage-0 ``arange``
-        samples) -> this regulariser -> soft-argmax.  [B,C,H,W] x2 -> pred [B,H,W] (, reg [B,D,H,W])."""
+        samples) -> this regulariser -> soft-argmax, through the single C entry ``decnet_stage0_forward``
+        (one workspace, one ctypes call).  [B,C,H,W] x2 -> pred [B,H,W] (, reg [B,D,H,W])."""
+        if self.training or (torch.is_grad_enabled() and (left_feature_map.requires_grad or
+                                                          right_feature_map.requires_grad)):
+            raise NotImplementedError("CostRegNetNoDown on gfx950 is inference-only: call "
+                                      ".eval() and run under torch.no_grad()")
         left = left_feature_map.contiguous()
         right = right_feature_map.contiguous()
+        _chk("left_feature_map", left)
         if left.shape[1] % 4:                           # see prepare()
             padc = (0, 0, 0, 0, 0, 4 - left.shape[1] % 4)
             left = torch.nn.functional.pad(left, padc)
             right = torch.nn.functional.pad(right, padc)
         B, C, H, W = left.shape
+        _chk("right_feature_map", right, (B, C, H, W))
         D = int(max_disp)
-        cv = self.costvol_buffer(left.device, B, D, H, W, C)
-        costvol_ndhwc(left, right, D, out=cv)
-        reg, pred = self.run_ndhwc(cv, want_reg=return_reg, want_pred=True)
+        algo = conv_algo(D)
+        P = self.prepare(D)
+        if P[0]["Ci"] != C:
+            raise ValueError("feature maps have %d channels, module expects %d"
+                             % (left_feature_map.shape[1], int(self.units()[0].conv.weight.shape[1])))
+        L = _lib.lib()
+        dev = left.device
+        variant = WINO_VARIANT.get(algo, 3)
+        pk = self._ws.get(("s0params", dev))
+        if pk is None or pk[0] is not P or pk[1] != variant:
+            sp = _lib.Stage0Params()
+            for i in range(7):
+                sp.w[i] = P[i]["u"].data_ptr() if variant <= 2 else P[i]["w"].data_ptr()
+                sp.scale[i], sp.shift[i] = P[i]["scale"].data_ptr(), P[i]["shift"].data_ptr()
+            sp.w_last, sp.scale_last, sp.shift_last = P[7]["w"].data_ptr(), P[7]["scale"], P[7]["shift"]
+            pk = (P, variant, sp)
+            self._ws[("s0params", dev)] = pk
+        n = L.decnet_stage0_workspace_floats(B, C, H, W, D, variant)
+        if n == 0:
+            raise _lib.DecnetHipError("decnet_stage0_forward: shape not supported")
+        ws = self._ws.get(("s0", dev))
+        if ws is None or ws.numel() < n:
+            ws = torch.empty(n, dtype=torch.float32, device=dev)
+            self._ws[("s0", dev)] = ws
+        reg = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if return_reg else None
+        pred = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        import ctypes
+        with torch.cuda.device(dev):
+            rc = L.decnet_stage0_forward(left.data_ptr(), right.data_ptr(), ctypes.byref(pk[2]), ws.data_ptr(),
+                                         reg.data_ptr() if reg is not None else None, pred.data_ptr(),
+                                         B, C, H, W, D, variant, _stream(left))
+        _lib.check(rc, "decnet_stage0_forward")
         return (pred, reg) if return_reg else pred
+
+    def stage0_buffers(self, dev, B, C, H, W, D):
+        """Views of the single-entry workspace (cost volume, first activation buffer, Winograd scratch): what
+        bench.py's roofline leg times the dominant kernel on."""
+        n = B * D * H * W * C
+        act = (n + 63) // 64 * 64
+        ws = self._ws[("s0", dev)]
+        return ws[:n].view(B, D, H, W, C), ws[act:act + n], ws[4 * act:]
 
 
 def disparity_regression(cost_vol, disp_samples):

@@ -164,6 +164,33 @@ int decnet_conv3d_cout1_softargmax_ws(const float *x, const float *w_oidhw, floa
                                       float shift, float *reg, float *pred, float *workspace,
                                       int B, int D, int H, int W, int Ci, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * The whole stage-0 branch in one call: replaces SparseDenseNetRefinementMask.forward :127-137, i.e.
+ * get_disp_samples (submodule.py:389-390) -> GetCostVolume.forward (:532-562) ->
+ * CostRegNetNoDown.forward (:650-662) -> disparity_regression (:766-777) for the shipped configuration
+ * (cost_func="cor", warp_ope="homgrp", 8 Conv3dUnits C -> C ... C -> 1).
+ *   left, right [B,C,H,W] feature maps of the coarsest level;  D = max_disp / 27 hypotheses 0 .. D-1
+ *   params      the seven C -> C layers: w[i] = decnet_conv3d_wino_pack_weight(...) of the layer for
+ *               variant 0..2 (decnet_conv3d_pack_weight for variant 3 = direct 27-tap GEMM), scale / shift =
+ *               folded BatchNorm3d [C]; the last layer: w_last [1,C,3,3,3] (torch layout), scale_last, shift_last
+ *   variant     -1 = automatic (F(4,3)^3 where depth tiles of 4 pay, else F(2,3)xF(4,3)^2), else as above
+ *   workspace   decnet_stage0_workspace_floats(B,C,H,W,D,variant) floats of device scratch (cost volume,
+ *               three ping-pong activation buffers, the Winograd intermediates); contents are scratch
+ *   reg         NULL or [B,D,H,W]: the regularised volume (what CostRegNetNoDown returns)
+ *   pred        [B,H,W]: the stage-0 disparity
+ * C must be a multiple of 4 (pad features and weights with zero channels otherwise).             */
+typedef struct decnet_stage0_params {
+    const float *w[7];
+    const float *scale[7];
+    const float *shift[7];
+    const float *w_last;
+    float scale_last, shift_last;
+} decnet_stage0_params;
+size_t decnet_stage0_workspace_floats(int B, int C, int H, int W, int D, int variant);
+int decnet_stage0_forward(const float *left, const float *right, const decnet_stage0_params *params,
+                          float *workspace, float *reg, float *pred, int B, int C, int H, int W, int D,
+                          int variant, void *stream);
+
 /* disparity_regression for arbitrary samples (submodule.py:766-777):
  *   cost, samples [B,S,H,W] -> pred [B,H,W]                                                */
 int decnet_disparity_regression(const float *cost, const float *samples, float *pred, int B,

@@ -4,7 +4,8 @@
 //   0  the three passes as shipped (max3 | fma, exp2, S+=, T=fma | d=imm+c, t=e*d, V=fma)
 //   1  per-tile moments: pass 2 keeps s = sum e, t = sum r e, q = sum r^2 e per tile (r = 0..3), S/T/V from them
 //   2  as 0 with four accumulator chains instead of two
-//   3  exp2 only (60 v_exp_f32)         4  60 independent v_fma_f32
+//   3  exp2 only (60 v_exp_f32)         4  60 independent v_fma_f32      8  the loop's overhead alone
+//   5/6  pass 2 in separated phases     7  max + 60 x (fma, exp2, add)
 // hipcc --offload-arch=gfx950 -O3 -fno-honor-nans softmax_rate.hip -o softmax_rate.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -32,6 +33,11 @@ __global__ __launch_bounds__(256, 4) void k(float *out, float seed, int D) {
             for (int m = 0; m < NT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) res += ex2(acc[m][r]);   // (adds included: 60 exp + 60 add)
+            continue;
+        }
+        if (V == 8) {                       // the loop's own overhead: making the 60 inputs, nothing else
+#pragma unroll
+            for (int m = 0; m < NT; ++m) res += (acc[m][0] + acc[m][1]) + (acc[m][2] + acc[m][3]);
             continue;
         }
         if (V == 4) {
@@ -209,6 +215,7 @@ int main() {
     float *d; hipMalloc(&d, 256 * 4 * 256 * 4);
     run<0>("three passes as shipped", d); run<1>("per-tile moments", d); run<2>("four accumulator chains", d);
     run<3>("60 x (exp2 + add)", d); run<4>("60 x fma", d);
+    run<8>("inputs only (loop overhead)", d);
     run<5>("phase-separated", d); run<6>("phase-separated, squares first", d); run<7>("max + 60 x (fma, exp2, add)", d);
     return 0;
 }
