@@ -288,7 +288,7 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
 
 // KQ = number of K=4 channel steps when known at compile time (C <= 4*KQ), 0 = runtime loop.
 template <int NT, int MODE, int KQ>
-__global__ __launch_bounds__(THREADS, 4) void spamat_fwd_mfma(
+__global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,

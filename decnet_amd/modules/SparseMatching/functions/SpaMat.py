@@ -22,9 +22,9 @@ class SpaMatFunction(Function):
         assert ref_feas.is_contiguous() and tar_feas.is_contiguous()        # SpaMat.py:21
         assert ref_mask.is_contiguous() and tar_mask.is_contiguous()        # SpaMat.py:22
         # the kernels write every element, so no zero fill (SpaMat.py:25-27 needs three)
-        output = torch.empty_like(ref_mask)
-        sum_similarities = torch.empty_like(ref_mask)
-        max_cost = torch.empty_like(ref_mask)
+        # (one allocation for the three planes: they live and die together in ctx)
+        output, sum_similarities, max_cost = torch.empty((3,) + tuple(ref_mask.shape), dtype=ref_mask.dtype,
+                                                         device=ref_mask.device).unbind(0)
         ops.spamat_forward(ref_feas, tar_feas, ref_mask, tar_mask, output, sum_similarities,
                            max_cost, max_disp)
         ctx.save_for_backward(ref_feas, tar_feas, ref_mask, tar_mask, output, sum_similarities,

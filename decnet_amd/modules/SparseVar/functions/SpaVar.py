@@ -22,9 +22,8 @@ class SpaVarFunction(Function):
         assert ref_feas.is_contiguous() and tar_feas.is_contiguous()        # SpaVar.py:21
         assert ref_mask.is_contiguous() and tar_mask.is_contiguous()        # SpaVar.py:22
         disparity = disparity.contiguous()
-        output = torch.empty_like(ref_mask)
-        sum_similarities = torch.empty_like(ref_mask)
-        max_cost = torch.empty_like(ref_mask)
+        output, sum_similarities, max_cost = torch.empty((3,) + tuple(ref_mask.shape), dtype=ref_mask.dtype,
+                                                         device=ref_mask.device).unbind(0)
         ops.spavar_forward(ref_feas, tar_feas, ref_mask, tar_mask, disparity, output,
                            sum_similarities, max_cost, max_disp)
         ctx.save_for_backward(ref_feas, tar_feas, ref_mask, tar_mask, disparity, output,

@@ -9,11 +9,23 @@ import torch
 from . import _lib
 
 
+_F32 = torch.float32
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    """The current HIP stream of t's device as a raw handle (what the C ABI takes as void*)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _chk(name, t, shape=None):
+    # fast path first: this runs for every tensor of every call (SpaMatFunction's host time is what is
+    # left of a training step at stages 1-2, bench.py `train`)
+    if (type(t) is torch.Tensor or isinstance(t, torch.Tensor)) and t.is_cuda and t.dtype is _F32 and \
+            t.is_contiguous() and (shape is None or t.shape == shape):
+        return t
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
     if not t.is_cuda:
@@ -24,9 +36,37 @@ def _chk(name, t, shape=None):
         raise TypeError("%s must be float32, got %s" % (name, t.dtype))
     if not t.is_contiguous():
         raise AssertionError("%s must be contiguous" % name)      # functions/SpaMat.py:21-22
-    if shape is not None and tuple(t.shape) != tuple(shape):
-        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
-    return t
+    raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+
+
+class _on_device:
+    """`with _on_device(t):` = torch.cuda.device(t.device), free when that device is already current (the
+    reference wraps its launches in torch.cuda.device_of, functions/SpaMat.py:24)."""
+    __slots__ = ("idx", "ctx")
+
+    def __init__(self, t):
+        self.idx = t.device.index
+        self.ctx = None
+
+    def __enter__(self):
+        if self.idx != torch.cuda.current_device():
+            self.ctx = torch.cuda.device(self.idx)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
+_FN = {}
+
+
+def _fn(name):
+    """ctypes entry point, looked up once."""
+    f = _FN.get(name)
+    if f is None:
+        f = _FN[name] = getattr(_lib.lib(), name)
+    return f
 
 
 def _same_device(*ts):
@@ -56,8 +96,8 @@ def spamat_forward(ref, tar, rmask, tmask, output, sum_sim, max_cost, max_disp):
     B, C, H, W, D = _feat_args(ref, tar, rmask, tmask, max_disp)
     for n, t in (("output", output), ("sum_similarities", sum_sim), ("max_cost", max_cost)):
         _chk(n, t, (B, H, W))
-    with torch.cuda.device(ref.device):
-        rc = _lib.lib().decnet_spamat_forward(
+    with _on_device(ref):
+        rc = _fn("decnet_spamat_forward")(
             ref.data_ptr(), tar.data_ptr(), rmask.data_ptr(), tmask.data_ptr(), output.data_ptr(),
             sum_sim.data_ptr(), max_cost.data_ptr(), B, C, H, W, D, _stream(ref))
     _lib.check(rc, "decnet_spamat_forward")
@@ -71,8 +111,8 @@ def spamat_backward(ref, tar, rmask, tmask, output, sum_sim, max_cost, grad_out,
         _chk(n, t, (B, H, W))
     _chk("grad_ref_feas", grad_ref, (B, C, H, W))
     _chk("grad_tar_feas", grad_tar, (B, C, H, W))
-    with torch.cuda.device(ref.device):
-        rc = _lib.lib().decnet_spamat_backward(
+    with _on_device(ref):
+        rc = _fn("decnet_spamat_backward")(
             ref.data_ptr(), tar.data_ptr(), rmask.data_ptr(), tmask.data_ptr(), output.data_ptr(),
             sum_sim.data_ptr(), max_cost.data_ptr(), grad_out.data_ptr(), grad_ref.data_ptr(),
             grad_tar.data_ptr(), B, C, H, W, D, _stream(ref))
@@ -84,8 +124,8 @@ def spavar_forward(ref, tar, rmask, tmask, disparity, output, sum_sim, max_cost,
     for n, t in (("disparity", disparity), ("output", output), ("sum_similarities", sum_sim),
                  ("max_cost", max_cost)):
         _chk(n, t, (B, H, W))
-    with torch.cuda.device(ref.device):
-        rc = _lib.lib().decnet_spavar_forward(
+    with _on_device(ref):
+        rc = _fn("decnet_spavar_forward")(
             ref.data_ptr(), tar.data_ptr(), rmask.data_ptr(), tmask.data_ptr(),
             disparity.data_ptr(), output.data_ptr(), sum_sim.data_ptr(), max_cost.data_ptr(),
             B, C, H, W, D, _stream(ref))
@@ -100,8 +140,8 @@ def spavar_backward(ref, tar, rmask, tmask, disparity, output, sum_sim, max_cost
         _chk(n, t, (B, H, W))
     _chk("grad_ref_feas", grad_ref, (B, C, H, W))
     _chk("grad_tar_feas", grad_tar, (B, C, H, W))
-    with torch.cuda.device(ref.device):
-        rc = _lib.lib().decnet_spavar_backward(
+    with _on_device(ref):
+        rc = _fn("decnet_spavar_backward")(
             ref.data_ptr(), tar.data_ptr(), rmask.data_ptr(), tmask.data_ptr(),
             disparity.data_ptr(), output.data_ptr(), sum_sim.data_ptr(), max_cost.data_ptr(),
             grad_out.data_ptr(), grad_ref.data_ptr(), grad_tar.data_ptr(), grad_disp.data_ptr(),
@@ -119,8 +159,8 @@ def spamatvar_forward(ref, tar, rmask, tmask, max_disp, out=None):
     o, v, s, m = out
     for n, t in (("output", o), ("variance", v), ("sum_similarities", s), ("max_cost", m)):
         _chk(n, t, (B, H, W))
-    with torch.cuda.device(ref.device):
-        rc = _lib.lib().decnet_spamatvar_forward(
+    with _on_device(ref):
+        rc = _fn("decnet_spamatvar_forward")(
             ref.data_ptr(), tar.data_ptr(), rmask.data_ptr(), tmask.data_ptr(), o.data_ptr(),
             v.data_ptr(), s.data_ptr(), m.data_ptr(), B, C, H, W, D, _stream(ref))
     _lib.check(rc, "decnet_spamatvar_forward")
