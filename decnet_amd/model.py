@@ -352,6 +352,46 @@ class GenerateSparseMask(nn.Module):
         d = self.conv_sub(cur) - self.deconv(pre)
         return self.conv(d * d).squeeze(1)
 
+    def _host_params(self):
+        """The 3x3 and 1x1 units of ``conv`` with BatchNorm folded, as host arrays (90 floats; one device ->
+        host copy per weight version)."""
+        import ctypes
+        u3, u1 = self.conv[0], self.conv[1]
+        ts = [t for u in (u3, u1) for t in (u.conv.weight, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var)]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_hp_key", None) != key:
+            with torch.no_grad():
+                def fold(u):
+                    sc = u.bn.weight.float() / torch.sqrt(u.bn.running_var.float() + u.bn.eps)
+                    return sc, u.bn.bias.float() - u.bn.running_mean.float() * sc
+                s3, b3 = fold(u3)
+                s1, b1 = fold(u1)
+                flat = torch.cat([u3.conv.weight.float().reshape(-1), s3, b3, u1.conv.weight.float().reshape(-1),
+                                  s1, b1]).cpu().tolist()
+            arr = lambda v: (ctypes.c_float * len(v))(*v)
+            self._hp = (arr(flat[0:81]), arr(flat[81:84]), arr(flat[84:87]), arr(flat[87:90]), flat[90], flat[91])
+            self._hp_key = key
+        return self._hp
+
+    def mask(self, cur, pre, thold):
+        """``(sigmoid(self(cur, pre)) > thold)`` as a float 0/1 plane [B,H,W] (SparseDenseNetRefinementMask.py:
+        148-170).  On the GPU in eval mode the squared difference, both convolutions of ``conv``, the sigmoid
+        and the threshold are one kernel (csrc/maskgen.hip)."""
+        if (self.training or not cur.is_cuda or cur.dtype != torch.float32 or torch.is_grad_enabled() or
+                os.environ.get("DECNET_CONV2D", "hip") != "hip" or cur.shape[-2] > 65535):
+            return (torch.sigmoid(self(cur, pre)) > thold).to(cur.dtype)
+        from . import _lib
+        from .ops import _stream
+        a, b = self.conv_sub(cur).contiguous(), self.deconv(pre).contiguous()
+        B, _, H, W = a.shape
+        w3, s3, b3, w1, s1, b1 = self._host_params()
+        out = torch.empty((B, H, W), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().decnet_detail_mask(a.data_ptr(), b.data_ptr(), w3, s3, b3, w1, s1, b1, float(thold),
+                                                     out.data_ptr(), None, None, B, H, W, _stream(a)),
+                       "decnet_detail_mask")
+        return out
+
 
 class DynamicUpsampling(nn.Module):
     """submodule.py:566-589: x3 upsampling of a disparity map with per-pixel softmax weights over
@@ -512,8 +552,8 @@ class SparseDenseNetRefinementMask(nn.Module):
                 continue
             if self.use_detail:                                           # reference :148-170
                 gen = self.detail_detection[stage - 1]
-                lmask = (torch.sigmoid(gen(L, pre_L)) > self.thold).to(L.dtype)
-                rmask = (torch.sigmoid(gen(R, pre_R)) > self.thold).to(R.dtype)
+                lmask = gen.mask(L, pre_L, self.thold)
+                rmask = gen.mask(R, pre_R, self.thold)
                 pre_L, pre_R = L, R
             else:
                 lmask, rmask = left_mask_list[stage - 1], right_mask_list[stage - 1]

@@ -231,6 +231,19 @@ int decnet_warp_disparity(const float *right, const float *disp, float *out, int
  * 3 * pixel_shuffle(sum_k softmax_k(logits) * replicate-padded 3x3 neighbours of disp). */
 int decnet_dynamic_upsample3(const float *logits, const float *disp, float *out, int B, int h, int w,
                              void *stream);
+/* Tail of GenerateSparseMask.forward + the thresholding of the model loop in one pass (submodule.py:366-372:
+ * res_info = (cur_fea - pre_fea)^2 -> Conv2dUnit(3,3,3x3,BN) -> Conv2dUnit(3,1,1x1,BN) = detail;
+ * SparseDenseNetRefinementMask.py:158-170: mask = sigmoid(detail) > thold ? 1 : 0).
+ *   cur3, pre3   [B,3,H,W] device: outputs of GenerateSparseMask.conv_sub / .deconv
+ *   w3x3 [3,3,3,3] (torch [co,ci,ky,kx]), scale3/shift3 [3], w1x1 [3], scale1, shift1: HOST values, BatchNorm
+ *                folded (scale = gamma / sqrt(var + eps), shift = beta - mean * scale); thold as float32
+ *   mask         [B,H,W] float 0/1 (the reference's contract: what SpaMat / SoftAttention read)
+ *   logits       NULL or [B,H,W]: `detail`
+ *   bits         NULL or [B,H,ceil(W/64)] 64-bit words, bit i of word w = pixel 64 w + i of the row       */
+int decnet_detail_mask(const float *cur3, const float *pre3, const float *w3x3, const float *scale3,
+                       const float *shift3, const float *w1x1, float scale1, float shift1, float thold,
+                       float *mask, float *logits, unsigned long long *bits, int B, int H, int W,
+                       void *stream);
 /* y[b,c,:,:] = act(y[b,c,:,:] + shift[c]) in place, y [B,C,H,W]: the folded-BatchNorm bias and the ReLU
  * behind a library convolution, one pass.  B*C <= 65535. */
 int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu,

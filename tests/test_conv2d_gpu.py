@@ -142,3 +142,34 @@ def test_unit_falls_back_when_not_covered(dev):
     with torch.no_grad():
         assert u._hip_kind(x) is None
         assert tuple(u(x).shape) == (1, 24, 300, 300)
+
+
+@pytest.mark.parametrize("H,W,thold", [(131, 517, 0.5), (67, 64, 0.9), (5, 1000, 0.3)])
+def test_mask_generator_tail_vs_torch_cpu(dev, H, W, thold):
+    """csrc/maskgen.hip: (cur - pre)^2 -> Conv2dUnit(3,3,3x3,BN) -> Conv2dUnit(3,1,1x1,BN) -> sigmoid -> > thold
+    (submodule.py:366-372, SparseDenseNetRefinementMask.py:158-170) against the same steps as torch CPU ops."""
+    from decnet_amd.model import GenerateSparseMask
+    torch.manual_seed(H)
+    gen = GenerateSparseMask(8, 3).eval()
+    for u in gen.conv:
+        u.bn.weight.data.uniform_(0.5, 1.5)
+        u.bn.bias.data.normal_(0, 0.3)
+        u.bn.running_mean.data.normal_(0, 0.2)
+        u.bn.running_var.data.uniform_(0.5, 1.5)
+    g = torch.Generator().manual_seed(W)
+    cur = torch.randn(2, 8, H, W, generator=g)
+    pre = torch.randn(2, 24, (H + 2) // 3, (W + 2) // 3, generator=g)
+    if H % 3 or W % 3:                                      # the model only ever sees exact x3 pairs
+        H, W = 3 * ((H + 2) // 3), 3 * ((W + 2) // 3)
+        cur = torch.randn(2, 8, H, W, generator=g)
+    with torch.no_grad():
+        logit = gen(cur, pre)                               # CPU: torch ops
+        sig = torch.sigmoid(logit)
+        ref = (sig > thold).float()
+        gen = gen.to(dev)
+        got = gen.mask(cur.to(dev), pre.to(dev), thold).cpu()
+    assert got.shape == ref.shape and set(got.unique().tolist()) <= {0.0, 1.0}
+    sure = (sig - thold).abs() > 1e-4                       # away from the threshold the bits must agree
+    assert bool((got == ref)[sure].all()), "mask differs away from the threshold"
+    assert float((got != ref).float().mean()) < 1e-3
+    assert 0.02 < float(ref.mean()) < 0.98                  # the case really has both values
