@@ -408,7 +408,19 @@ class DynamicUpsampling(nn.Module):
     def forward(self, disp, fea):
         B, h, w = disp.shape
         s2 = self.s ** 2
-        wts = torch.cat((disp.unsqueeze(1), F.unfold(fea, self.s, stride=self.s).view(B, -1, h, w)), 1)
+        hip = (self.s == 3 and fea.is_cuda and fea.dtype == torch.float32 and not torch.is_grad_enabled() and
+               h <= 65535 and B * (fea.shape[1] + 1) <= 65535 and os.environ.get("DECNET_CONV2D", "hip") == "hip" and
+               tuple(fea.shape[-2:]) == (3 * h, 3 * w))
+        if hip:                                         # cat(disp, unfold(fea)) as one pass (csrc/unfold.hip)
+            from . import _lib
+            from .ops import _stream
+            f, dp = fea.contiguous(), disp.contiguous()
+            wts = torch.empty((B, 9 * f.shape[1] + 1, h, w), dtype=torch.float32, device=f.device)
+            with torch.cuda.device(f.device):
+                _lib.check(_lib.lib().decnet_unfold3_cat(f.data_ptr(), dp.data_ptr(), wts.data_ptr(), B, f.shape[1], h, w,
+                                                         _stream(f)), "decnet_unfold3_cat")
+        else:
+            wts = torch.cat((disp.unsqueeze(1), F.unfold(fea, self.s, stride=self.s).view(B, -1, h, w)), 1)
         logits = self.weight_learning(wts)
         if (self.s == 3 and logits.is_cuda and logits.dtype == torch.float32 and not torch.is_grad_enabled() and
                 h <= 65535 and os.environ.get("DECNET_CONV2D", "hip") == "hip"):

@@ -244,6 +244,10 @@ int decnet_detail_mask(const float *cur3, const float *pre3, const float *w3x3, 
                        const float *shift3, const float *w1x1, float scale1, float shift1, float thold,
                        float *mask, float *logits, unsigned long long *bits, int B, int H, int W,
                        void *stream);
+/* Head of DynamicUpsampling.forward (submodule.py:578-580): out = cat(disp, unfold(fea, 3, stride 3)):
+ * fea [B,C,3h,3w], disp [B,h,w] -> out [B,9C+1,h,w], out[b,0] = disp, out[b,1+9c+3i+j,y,x] = fea[b,c,3y+i,3x+j]. */
+int decnet_unfold3_cat(const float *fea, const float *disp, float *out, int B, int C, int h, int w,
+                       void *stream);
 /* y[b,c,:,:] = act(y[b,c,:,:] + shift[c]) in place, y [B,C,H,W]: the folded-BatchNorm bias and the ReLU
  * behind a library convolution, one pass.  B*C <= 65535. */
 int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu,

@@ -144,8 +144,8 @@ def test_unit_falls_back_when_not_covered(dev):
         assert tuple(u(x).shape) == (1, 24, 300, 300)
 
 
-@pytest.mark.parametrize("H,W,thold", [(131, 517, 0.5), (67, 64, 0.9), (5, 1000, 0.3)])
-def test_mask_generator_tail_vs_torch_cpu(dev, H, W, thold):
+@pytest.mark.parametrize("H,W,quant", [(131, 517, 0.5), (67, 64, 0.9), (5, 1000, 0.3)])
+def test_mask_generator_tail_vs_torch_cpu(dev, H, W, quant):
     """csrc/maskgen.hip: (cur - pre)^2 -> Conv2dUnit(3,3,3x3,BN) -> Conv2dUnit(3,1,1x1,BN) -> sigmoid -> > thold
     (submodule.py:366-372, SparseDenseNetRefinementMask.py:158-170) against the same steps as torch CPU ops."""
     from decnet_amd.model import GenerateSparseMask
@@ -165,6 +165,7 @@ def test_mask_generator_tail_vs_torch_cpu(dev, H, W, thold):
     with torch.no_grad():
         logit = gen(cur, pre)                               # CPU: torch ops
         sig = torch.sigmoid(logit)
+        thold = float(sig.flatten().quantile(quant))        # a threshold that splits this case's pixels
         ref = (sig > thold).float()
         gen = gen.to(dev)
         got = gen.mask(cur.to(dev), pre.to(dev), thold).cpu()
@@ -173,3 +174,19 @@ def test_mask_generator_tail_vs_torch_cpu(dev, H, W, thold):
     assert bool((got == ref)[sure].all()), "mask differs away from the threshold"
     assert float((got != ref).float().mean()) < 1e-3
     assert 0.02 < float(ref.mean()) < 0.98                  # the case really has both values
+
+
+def test_unfold3_cat_vs_torch(dev):
+    """csrc/unfold.hip against torch.cat((disp, F.unfold(fea, 3, stride=3))) (submodule.py:578-580): exact."""
+    import torch.nn.functional as F
+    from decnet_amd import _lib
+    g = torch.Generator().manual_seed(2)
+    B, C, h, w = 2, 5, 7, 300
+    fea = torch.randn(B, C, 3 * h, 3 * w, generator=g)
+    disp = torch.randn(B, h, w, generator=g)
+    ref = torch.cat((disp.unsqueeze(1), F.unfold(fea, 3, stride=3).view(B, -1, h, w)), 1)
+    f, d = fea.to(dev), disp.to(dev)
+    out = torch.empty(B, 9 * C + 1, h, w, device=dev)
+    _lib.check(_lib.lib().decnet_unfold3_cat(f.data_ptr(), d.data_ptr(), out.data_ptr(), B, C, h, w,
+                                             torch.cuda.current_stream().cuda_stream), "decnet_unfold3_cat")
+    assert torch.equal(out.cpu(), ref)
