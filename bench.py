@@ -514,8 +514,8 @@ def main_train(args, B, dev, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
                     help="BASELINE.json config (2 = the metric's; 3, 4: the other single-GPU-shard shapes)")
     ap.add_argument("--pairs-per-gpu", type=int, default=0, help="default: the config's (8 / 4 / 1 / 4)")

@@ -38,6 +38,22 @@ def test_bench_line_contract():
     assert cv["bound"] == "hbm" and cv["peak"] == 8000.0 and 0 < cv["frac"] < 1.2
 
 
+def test_bench_train_leg_full_size():
+    """The config-5 share at full size (4 pairs of 972x540, stages 1-3, forward + backward through the C ABI and
+    through SpaMatFunction) under a test assertion, not only inside the driver's bench run; and --config 5 itself."""
+    d = _run("--no-e2e", "--no-density-sweep", "--no-cpu-baseline")
+    tr = d["train"]
+    assert "error" not in tr, tr
+    for row in tr["by_density"]:
+        assert [s["stage"] for s in row["stages"]] == [1, 2, 3]
+        for s in row["stages"]:
+            assert s["fwd_kernel_ms"] > 0 and s["bwd_kernel_ms"] > 0 and s["autograd_step_ms"] >= s["bwd_kernel_ms"] * 0.5
+            assert 0 < s["bwd_frac_hbm"] < 1.0
+    d5 = _run("--config", "5")
+    assert d5["n_gpus"] == 1 and d5["value"] > 0 and "config 5" in d5["config"]["workload"]
+    assert d5["roofline"]["bound"] == "hbm" and 0 < d5["roofline"]["frac"] < 1.0 and d5["config"]["grad_buckets"] == 4
+
+
 def test_bench_other_configs_run():
     for cfg in ("3", "4"):
         d = _run("--config", cfg, "--no-e2e", "--no-train", "--no-density-sweep", "--no-cpu-baseline")

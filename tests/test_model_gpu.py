@@ -122,3 +122,26 @@ def test_demo_with_host_detail_masks(tmp_path):
     with torch.no_grad():
         pred = model(demo.transform(lp).to(dev), demo.transform(rp).to(dev), None, lm, rm)[-1]
     assert np.array_equal(demo.disparity_to_uint16(pred, 54, 81), img)
+
+
+def test_data_parallel_replicas_share_nothing_mutable():
+    """eval.py:145-146 drives the reference through torch.nn.DataParallel: replicas of the module run on worker
+    threads.  The stage-0 wrapper used to live outside nn.Module bookkeeping, so replicas kept pointing at the
+    original's weights.  Two replicas (both on cuda:0: one GPU here) on two threads must give the
+    original module's result."""
+    from make_golden import E2E_KW, e2e_inputs
+    from torch.nn.parallel import parallel_apply, replicate
+    from decnet_amd.model import get_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    model = get_model(**E2E_KW).to(dev).eval()
+    left, right = (t.to(dev) for t in e2e_inputs())
+    left2, right2 = left.flip(-1).contiguous(), right.flip(-1).contiguous()
+    with torch.no_grad():
+        want = [model(left, right)[-1].clone(), model(left2, right2)[-1].clone()]
+        reps = replicate(model, [0, 0])
+        assert reps[0].cost_regularizer is not model.cost_regularizer
+        assert reps[0].cost_regularizer.conv0[0].conv.weight.data_ptr() != model.cost_regularizer.conv0[0].conv.weight.data_ptr()
+        got = parallel_apply(reps, [(left, right), (left2, right2)])
+    for w, g in zip(want, got):
+        assert float((w - g[-1]).abs().max()) < 1e-4
