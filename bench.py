@@ -186,14 +186,16 @@ def time_kernel(fn, iters, warm=10):
     return beg.elapsed_time(end) / iters          # ms per call
 
 
-def valu_floor(n_wave_tiles, n_mfma_per_tile=30):
+def valu_floor(n_wave_tiles, n_mfma_per_tile=30, mfma_issue_cycles=8):
     """The instruction-issue floor of the dense stage-3 cost-volume pass, measured live: tools/ubench/
     softmax_rate.bin (built by __graft_entry__.build(); run as a child process) times nothing but the VALU work
     of the kernel's softmax passes -- 60 candidates per lane, the 'per-tile moments' formulation the kernel
     uses, 4 waves per SIMD on every CU -- and the loop overhead of the microbenchmark itself, which is
-    subtracted.  The fp32 MFMAs of a wave-tile (v_mfma_f32_16x16x4_f32: 32 cycles each on the SIMD's FP32
-    lanes, which the VALU passes use too: the two add, they do not overlap -- ablation builds) are
-    priced at the nominal 2.4 GHz.  floor = wave-tiles per SIMD x (softmax time + MFMA time) per wave-tile."""
+    subtracted.  The MFMAs of a wave-tile are priced by the cycles they hold the SIMD's vector issue port at the
+    nominal 2.4 GHz: 8 of its 16 cycles for v_mfma_f32_16x16x32_bf16 (the default dense path: bf16x3 cost tiles, the
+    matrix pipe works beside the other waves' VALU passes), all 32 for v_mfma_f32_16x16x4_f32
+    (DECNET_SPAMAT_DENSE=fp32: fp32 MFMA runs on the FP32 lanes the VALU passes use, the two add -- ablation builds,
+    DESIGN.md).  floor = wave-tiles per SIMD x (softmax time + MFMA issue time) per wave-tile."""
     import re
     import subprocess
     exe = os.path.join(ROOT, "tools", "ubench", "softmax_rate.bin")
@@ -208,7 +210,7 @@ def valu_floor(n_wave_tiles, n_mfma_per_tile=30):
         return None
     ub_tiles_per_simd = 256 * 4 * 4 * 512 / 1024.0      # the microbenchmark's grid: blocks x waves x iterations / SIMDs
     soft_us = 1e3 * (ms["per-tile moments"] - ms["inputs only (loop overhead)"]) / ub_tiles_per_simd
-    mfma_us = n_mfma_per_tile * 32 / 2400.0
+    mfma_us = n_mfma_per_tile * mfma_issue_cycles / 2400.0
     per_simd = n_wave_tiles / 1024.0
     return {"softmax_us_per_wave_tile": soft_us, "mfma_us_per_wave_tile": mfma_us,
             "floor_ms": per_simd * (soft_us + mfma_us) * 1e-3, "floor_softmax_only_ms": per_simd * soft_us * 1e-3,
@@ -661,14 +663,17 @@ def main():
             # the dense pass against the bound that applies to it: instruction issue (VALU + fp32 MFMA)
             valu = None
             if args.mask_density >= 1.0:
-                vf = valu_floor(B * H3 * ((W3 + 15) // 16))
+                fp32_dense = os.environ.get("DECNET_SPAMAT_DENSE", "") == "fp32"
+                vf = valu_floor(B * H3 * ((W3 + 15) // 16), 30, 32 if fp32_dense else 8)
                 if vf:
                     valu = {"bound": "valu", "achieved": vf["floor_ms"], "peak": s3_ms, "unit": "ms (floor / measured)",
                             "frac": vf["floor_ms"] / s3_ms, "traffic": None, "ms": s3_ms,
                             "kernel": "spamat fused fwd, stage 3, mask density 1.0", "detail": vf,
                             "note": "frac = issue floor of the kernel's own arithmetic / measured time: the softmax "
-                                    "VALU passes of its 60 candidates per lane (microbenchmark, live) + its 30 fp32 "
-                                    "MFMAs per wave-tile, both on the SIMDs' FP32 lanes"}
+                                    "VALU passes of its 60 candidates per lane (microbenchmark, live) + the vector-issue "
+                                    "cycles of its 30 MFMAs per wave-tile (%s)" % (
+                                        "fp32 MFMA, 32 cycles each" if fp32_dense else "bf16x3 on v_mfma_f32_16x16x32_bf16, "
+                                        "8 cycles each")}
         out = {
             "metric": ("stereo pairs/sec at 960x540x192disp" if args.config == 2 else
                        "stereo pairs/sec, BASELINE config %d shapes" % args.config) +

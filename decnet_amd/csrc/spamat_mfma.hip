@@ -32,6 +32,7 @@
 // Compiled with -fno-honor-nans (build.py): otherwise every fmaxf on an MFMA result costs an
 // extra canonicalising v_max.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -40,6 +41,8 @@
 #endif                    // tools/ablate.sh; results are wrong by construction)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -65,6 +68,25 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, in
     return v;
 }
 
+// fp32 -> three bf16 terms x = hi + mid + lo (truncations with exact residuals: 24 mantissa bits
+// together), 8 values -> three packed 8 x bf16 MFMA operands.
+__device__ __forceinline__ void split3x8(const float (&x)[8], i32x4 &hi, i32x4 &mid, i32x4 &lo) {
+    int h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = __float_as_int(x[e]) & 0xffff0000;
+        const float r1 = x[e] - __int_as_float(h[e]);
+        m[e] = __float_as_int(r1) & 0xffff0000;
+        l[e] = __float_as_int(r1 - __int_as_float(m[e]));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                       // {x[2e+1][31:16], x[2e][31:16]}
+        hi[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302);
+        mid[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302);
+        lo[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302);
+    }
+}
+
 // LDS layout (4-byte words).  The channel pitch RP is == 16 (mod 32) so that the four channel
 // rows an MFMA operand fetch touches (lanes 0-15 / 16-31 / 32-47 / 48-63) never share a bank.
 //   Rs [Cq][RP]   R[c][xs - HALO + j];  column RP-1 is kept zero (target of padded gathers)
@@ -77,14 +99,17 @@ struct Layout {
     int SW, HALO, RP, Cq;
     int offR, offBX, offRK, offLM, offXL, offWT, total;
 };
-__host__ __device__ inline Layout make_layout(int C, int NT, int XT) {
+__host__ __device__ inline Layout make_layout(int C, int NT, int XT, bool d16 = false) {
     Layout l;
     l.SW = XT * 16;
     l.HALO = (NT - 1) * 16;
     l.Cq = (C + 3) & ~3;
     l.RP = ((l.HALO + l.SW + 31) & ~31) + 16;
     l.offR = 0;
-    l.offBX = l.offR + l.Cq * l.RP;
+    // (D16: the same region holds both views as bf16 terms, dense16_body)
+    const int swh = ((XT + 1) / 2) * 16;                             // dense16_body runs on half a segment at a time
+    const int rt = d16 ? 3 * ((C + 7) / 8) * (l.HALO + 2 * swh) * 4 : 0;
+    l.offBX = l.offR + (l.Cq * l.RP > rt ? l.Cq * l.RP : rt);
     l.offRK = l.offBX + l.RP;
     l.offLM = l.offRK + l.RP + 4;
     l.offXL = l.offLM + l.SW + 16;
@@ -286,20 +311,167 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
     mx_o = mx; S_o = S; mu_o = mu; var_o = var;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Dense rows on the bf16 matrix cores (dense path of spamat_fwd_mfma<.., D16 = true>).
+//
+// The fp32 MFMAs of the band kernel above run on the SIMDs' FP32 lanes: their 960 cycles per wave-tile
+// (30 x v_mfma_f32_16x16x4_f32) ADD to the softmax VALU passes (ablation builds), a quarter of the
+// dense pass.  Here cost[x'][x] = sum_c R[c][x'] L[c][x] is computed with both operands as three bf16 terms
+// (hi + mid + lo = the 24 mantissa bits, truncations with exact residuals) and every term pair except lo*lo
+// (2^-32) in the K axis of two v_mfma_f32_16x16x32_bf16 per 8 channels:
+//     k group (lane >> 4)      0        1        2        3
+//     "big"   MFMA  (A, B)   (hi,hi)  (hi,mid) (mid,hi) (mid,mid)
+//     "small" MFMA  (A, B)   (hi,lo)  (lo,hi)  (mid,lo) (lo,mid)
+// Products of bf16 are exact and the accumulation is fp32: fp32 accuracy, on a pipe that works beside the other
+// waves' VALU passes and holds the issue port 8 cycles per MFMA instead of 32.  What made this pay (a first
+// version that split the left features per 16-pixel tile in registers was no faster): BOTH feature rows are
+// split ONCE per workgroup while they are staged -- RT / LT [3 terms][C/8][position][8 ch x bf16], 16 bytes
+// per term, channel group and position -- so an MFMA operand is one ds_read_b128 and the splitting costs
+// ~5 % of the softmax work instead of ~20 %.  LDS: 48 bytes per staged position and channel group for each
+// side, so a 972-pixel row of stage 3 is two segments (63 KB each, two workgroups per CU).
+// BX (right-mask bias) and LM (left mask) are filled by the caller's phase 1.
+template <int NT, int MODE, int CGT>
+__device__ __forceinline__ void dense16_body(int *RT, const float *BX, const float *LM, const float *smem,
+                                             const float *__restrict__ lrow, const float *__restrict__ rrow,
+                                             const float *__restrict__ disparity, float *__restrict__ out,
+                                             float *__restrict__ var_out, float *__restrict__ sum_sim,
+                                             float *__restrict__ max_cost, size_t plane, size_t rowpix, int C, int W,
+                                             int D, int xs, int XT, int SW, int HALO, int nRw) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    struct { int CG; } lo = {(C + 7) >> 3};
+    int *LT = RT + 3 * lo.CG * nRw * 4;
+    // ---- features of both views: 8 channels x 4 positions per item, split into the three bf16 terms
+    {
+        const bool al = ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+        const int cg_n = lo.CG, nqR = nRw >> 2, nqL = SW >> 2;
+        const int nR_items = cg_n * nqR, n_items = nR_items + cg_n * nqL;
+#pragma unroll 1
+        for (int it = tid; it < n_items; it += THREADS) {
+            const bool isL = it >= nR_items;
+            const int k = isL ? it - nR_items : it, nq = isL ? nqL : nqR;
+            const int g = k / nq, jq = k - g * nq;
+            const float *src = isL ? lrow : rrow;
+            const int x = isL ? xs + 4 * jq : xs - HALO + 4 * jq;
+            float4 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                v[c] = 8 * g + c < C ? load4(src + (size_t)(8 * g + c) * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+            int *dst = (isL ? LT : RT) + (g * (isL ? SW : nRw) + 4 * jq) * 4;
+            const int tstride = cg_n * (isL ? SW : nRw) * 4;              // words between terms
+#pragma unroll
+            for (int pz = 0; pz < 4; ++pz) {
+                float xv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) xv[c] = pz == 0 ? v[c].x : pz == 1 ? v[c].y : pz == 2 ? v[c].z : v[c].w;
+                i32x4 th, tm, tl;
+                split3x8(xv, th, tm, tl);
+                *reinterpret_cast<i32x4 *>(dst + pz * 4) = th;
+                *reinterpret_cast<i32x4 *>(dst + tstride + pz * 4) = tm;
+                *reinterpret_cast<i32x4 *>(dst + 2 * tstride + pz * 4) = tl;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int j = lane & 15, q = lane >> 4;
+    const int dl = j - 4 * q;                                            // d = 16 m + dl - r
+    constexpr int CGB = CGT ? CGT : 1;
+    const int cg_n = CGT ? CGT : lo.CG;
+    // term of this lane's k group: A (right) big {hi,hi,mid,mid}, small {hi,lo,mid,lo}; B (left) big {hi,mid,hi,mid},
+    // small {lo,hi,lo,mid}
+    const int tA_big = q >> 1, tA_small = q == 0 ? 0 : q == 2 ? 1 : 2;
+    const int tB_big = q & 1, tB_small = q == 1 ? 0 : q == 3 ? 1 : 2;
+    const int gsR = nRw * 4, gsL = SW * 4;                               // words between channel groups
+    for (int xt = wave; xt < XT; xt += NWAVE) {
+        const int x0 = xs + xt * 16;
+        if (x0 >= W) break;
+        const int x = x0 + j;
+        const size_t pix = rowpix + x;
+        const bool inside = x < W;
+        const float rm = LM[xt * 16 + j];
+        if (__ballot(rm != 0.f) == 0ull) {                               // no active left pixel in this tile
+            if (inside && q == 0) {
+                if (MODE != MODE_VAR) out[pix] = 0.f;
+                if (MODE != MODE_MAT) var_out[pix] = 0.f;
+                sum_sim[pix] = 0.f;
+                max_cost[pix] = 0.f;
+            }
+            continue;
+        }
+        f32x4 acc[NT];
+        // right-mask bias (0 / -1e30 per right pixel = tile row) as the initial accumulator: 0 + x is exact and
+        // -1e30 + x = -1e30 (SM_kernel.cu:48 skips those candidates; positions left of the image are -1e30 too)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const float4 bz = *reinterpret_cast<const float4 *>(BX + (HALO + xt * 16) + 4 * q - 16 * m);
+            acc[m] = f32x4{bz.x, bz.y, bz.z, bz.w};
+        }
+        // tile m holds right pixels x0 - 16 m + (0..15); the lowest tile (m = NT-1) is the base address
+        const int *a_small = RT + (tA_small * cg_n * nRw + xt * 16 + j) * 4;
+        const int *a_big = RT + (tA_big * cg_n * nRw + xt * 16 + j) * 4;
+        const int *b_small = LT + (tB_small * cg_n * SW + xt * 16 + j) * 4;
+        const int *b_big = LT + (tB_big * cg_n * SW + xt * 16 + j) * 4;
+#if !(DECNET_ABLATE & 1)
+#pragma unroll
+        for (int g = 0; g < CGB; ++g) {
+            for (int gg = g; gg < cg_n; gg += CGB) {                     // CGT > 0: exactly one trip
+                const i32x4 bs = *reinterpret_cast<const i32x4 *>(b_small + gg * gsL);
+                const i32x4 bb = *reinterpret_cast<const i32x4 *>(b_big + gg * gsL);
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const i32x4 av = *reinterpret_cast<const i32x4 *>(a_small + gg * gsR + (NT - 1 - m) * 64);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                     __builtin_bit_cast(bf16x8, bs), acc[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const i32x4 av = *reinterpret_cast<const i32x4 *>(a_big + gg * gsR + (NT - 1 - m) * 64);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                     __builtin_bit_cast(bf16x8, bb), acc[m], 0, 0, 0);
+                }
+            }
+        }
+#else
+        acc[0][0] += __int_as_float(*(a_small + 3) ^ *(a_big + 5) ^ *(b_small + 1) ^ *(b_big + 2)) * 1e-30f;
+#endif
+#if DECNET_ABLATE & 2
+        {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) asm volatile("" :: "v"(acc[m]));
+            if (inside && q == 0) { out[pix] = acc[0][0]; var_out[pix] = 0.f; sum_sim[pix] = 0.f; max_cost[pix] = rm; }
+            continue;
+        }
+#endif
+        float mx, S, mu, var;
+        const float mu_in = (MODE == MODE_VAR && inside) ? disparity[pix] : 0.f;
+        softmax_passes<NT, MODE, false>(acc, NT, D, dl, smem, 0, 0, 0, mu_in, mx, S, mu, var);
+        if (inside && q == 0) {
+            const bool on = rm != 0.f;
+            if (MODE != MODE_VAR) out[pix] = on ? mu : 0.f;
+            if (MODE != MODE_MAT) var_out[pix] = on ? var : 0.f;
+            sum_sim[pix] = on ? S : 0.f;
+            max_cost[pix] = on ? mx : 0.f;
+        }
+    }
+
+}
+
 // KQ = number of K=4 channel steps when known at compile time (C <= 4*KQ), 0 = runtime loop.
-template <int NT, int MODE, int KQ>
-__global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
+// D16: dense rows go through dense16_body (bf16 matrix cores) instead of the fp32 MFMA band path.
+template <int NT, int MODE, int KQ, bool D16>
+__device__ __forceinline__ void spamat_fwd_segment(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker) {
+    int H, int W, int D, int XT, int allow_compact, int marker, int seg, int row) {
     // marker: this launch follows spamat_fwd_sparse, which left -1 in sum_sim[row start] of exactly
     // the rows it did not take, at the first pixel of every segment (a real sum_similarities is never
     // negative)
-    if (marker && sum_sim[(size_t)(blockIdx.x / segs_per_row) * W + (size_t)(blockIdx.x % segs_per_row) * (XT * 16)] != -1.0f)
+    if (marker && sum_sim[(size_t)row * W + (size_t)seg * (XT * 16)] != -1.0f)
         return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const Layout lo = make_layout(C, NT, XT);
+    const Layout lo = make_layout(C, NT, XT, D16);
     float *Rs = smem + lo.offR;
     float *BX = smem + lo.offBX;
     int *XR = reinterpret_cast<int *>(BX);
@@ -313,7 +485,6 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
     constexpr int KB = KQ ? KQ : 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg = blockIdx.x % segs_per_row, row = blockIdx.x / segs_per_row;
     const int b = row / H, y = row - b * H;
     const int xs = seg * SW;
     const int nRw = HALO + SW;                       // staged right positions (multiple of 16)
@@ -351,6 +522,33 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
         if (lane == 63) { WT[wave] = ir; WT[8 + wave] = il; }
     }
 
+    int nR = 0, nL = 0;
+    bool compact = false;
+    if constexpr (D16) {
+        // the row's path decides the LDS format of the features, so the counts come first
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
+        const int validL = min(SW, W - xs);
+        const int validR = min(W, xs + SW) - max(0, xs - HALO);
+        compact = allow_compact && ((long)nL * nR * 5 < (long)validL * validR * 4);
+        if (!compact) {
+            // two passes over half the segment each: both views as bf16 terms need 96 bytes of LDS per pixel and
+            // channel group, and the segment partition (= the number of workgroups of a marker launch, the
+            // compact path's halos) stays the fp32 layout's
+            const int xta = (XT + 1) / 2, xtb = XT - xta;
+            dense16_body<NT, MODE, (KQ + 1) / 2>(reinterpret_cast<int *>(Rs), BX, LM, smem, lrow, rrow, disparity, out,
+                                                 var_out, sum_sim, max_cost, plane, rowpix, C, W, D, xs, xta, xta * 16,
+                                                 HALO, HALO + xta * 16);
+            if (xtb > 0 && xs + xta * 16 < W) {
+                __syncthreads();
+                dense16_body<NT, MODE, (KQ + 1) / 2>(reinterpret_cast<int *>(Rs), BX + xta * 16, LM + xta * 16, smem, lrow,
+                                                     rrow, disparity, out, var_out, sum_sim, max_cost, plane, rowpix, C,
+                                                     W, D, xs + xta * 16, xtb, xtb * 16, HALO, HALO + xtb * 16);
+            }
+            return;
+        }
+    }
     // ---------------- phase 2: stage R.  Threads are spread over (channel row, group of 4 positions): a row
     // of the staged window takes nRw/4 threads, the rest of the workgroup takes further channel rows, and
     // every thread has up to 8 loads in flight before its stores (stage 1, C = 72 over 144 positions:
@@ -383,17 +581,18 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
     return;
 #endif
 
-    int nR = 0, nL = 0;
-#pragma unroll
-    for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
     const int validL = min(SW, W - xs);
     const int validR = min(W, xs + SW) - max(0, xs - HALO);
-    // compact when fewer than 80 % of the candidate pairs are active (block-uniform)
-    const bool compact = allow_compact && ((long)nL * nR * 5 < (long)validL * validR * 4);
+    if constexpr (!D16) {
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
+        // compact when fewer than 80 % of the candidate pairs are active (block-uniform)
+        compact = allow_compact && ((long)nL * nR * 5 < (long)validL * validR * 4);
+    }
 
     const int j = lane & 15, q = lane >> 4;
 
-    if (!compact) {
+    if constexpr (!D16) if (!compact) {
         // =========================== DENSE path ===========================================
         const int dl = j - 4 * q;                       // d = 16*m + dl - r
         float bv[KQ <= 6 ? KB : 1], bcur[KB];
@@ -614,6 +813,21 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
     }
 }
 
+// The kernel: one workgroup per segment of a row.  (Taking the two segments the bf16 layout makes of a stage-3 row
+// in one workgroup, one after the other, halves the exiting workgroups of an all-sparse marker launch (-2 us) but
+// serialises a dense row's two staging phases: 0.41 -> 0.44 ms at density 1.0; a loop over segments around the
+// inlined body costs ~20 VGPR spills on top.  Measured, dropped.)
+template <int NT, int MODE, int KQ, bool D16>
+__global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
+    float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
+    int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker) {
+    spamat_fwd_segment<NT, MODE, KQ, D16>(ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W,
+                                          D, XT, allow_compact, marker, blockIdx.x % segs_per_row,
+                                          blockIdx.x / segs_per_row);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Sparse rows (<= 256 active pixels on each side, i.e. up to ~26 % density at stage 3): nothing but
 // the masks and the features of the ACTIVE pixels is touched.  The kernel above stages the whole
@@ -830,7 +1044,11 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
               int B, int C, int H, int W, int D, int allow_compact, hipStream_t stream) {
     const int xt_row = ceil_div(W, 16);
-    auto bytes = [&](int xt) { return (size_t)4 * make_layout(C, NT, xt).total; };
+    // dense rows on the bf16 matrix cores (dense16_body) for the shipped channel counts (C = 8, 24) unless
+    // DECNET_SPAMAT_DENSE=fp32 or the compaction paths are pinned off; it needs more LDS per staged position
+    static const int dense_fp32 = [] { const char *e = getenv("DECNET_SPAMAT_DENSE"); return e && !strcmp(e, "fp32"); }();
+    const bool d16 = KQ == 2 && !dense_fp32;          // C = 24: three channel groups to split, measured slower (0.084 vs 0.063 ms)
+    auto bytes = [&](int xt) { return (size_t)4 * make_layout(C, NT, xt, d16).total; };
     // whole row per workgroup when two workgroups (16 waves) still fit a CU's LDS; otherwise
     // equal segments that do; otherwise whatever fits once.  Segments hold <= 64 tiles so that
     // one thread covers 4 pixels of the mask scan.
@@ -848,12 +1066,13 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     XT = (XT + 1) & ~1;                               // segment starts stay 32-float aligned
     if (XT > 64) XT = 64;
     const size_t lds = bytes(XT);
-    if (lds > budget1 || make_layout(C, NT, XT).RP > 2048) return DECNET_ERR_UNSUPPORTED;
+    if (lds > budget1 || make_layout(C, NT, XT, d16).RP > 2048) return DECNET_ERR_UNSUPPORTED;
     const int segs = ceil_div(xt_row, XT);
-    dim3 grid((unsigned)((size_t)B * H * segs)), block(THREADS);
+    dim3 block(THREADS);
     // sparse rows first (KQ > 0: C <= 24; rows of <= 2048 pixels), the rest by the marker launch
     static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
     const int marker = allow_compact && !sparse_off && KQ > 0 && KQ <= 6 && W <= 2048;
+    dim3 grid((unsigned)((size_t)B * H * segs));
     if constexpr (KQ > 0 && KQ <= 6) if (marker) {
         const int ppt = W <= 1024 ? 4 : 8;
         const size_t slds = 4 * (size_t)(SP_CAP + 16 + 2 * (SP_THREADS * ppt / 2 + 2) + SP_CAP + 16 +
@@ -882,20 +1101,30 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         const int rc = decnet_launch_status();
         if (rc) return rc;
     }
-#define LAUNCH(M)                                                                                  \
+#define LAUNCH1(M, DD)                                                                             \
     do {                                                                                           \
         if (lds > 64 * 1024) {                                                                     \
-            hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_mfma<NT, M, KQ>,           \
+            hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_mfma<NT, M, KQ, DD>,       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return (int)e;                                                    \
         }                                                                                          \
-        hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ>), grid, block, lds, stream, ref, tar, rmask, \
+        hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ, DD>), grid, block, lds, stream, ref, tar, rmask, \
                            tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT, \
                            allow_compact, marker);                                                 \
+    } while (0)
+#define LAUNCH(M)                                                                                  \
+    do {                                                                                           \
+        if constexpr (KQ == 2) {                                                                   \
+            if (d16) LAUNCH1(M, true);                                                             \
+            else LAUNCH1(M, false);                                                                \
+        } else {                                                                                   \
+            LAUNCH1(M, false);                                                                     \
+        }                                                                                          \
     } while (0)
     if (mode == MODE_MAT) LAUNCH(MODE_MAT);
     else if (mode == MODE_VAR) LAUNCH(MODE_VAR);
     else LAUNCH(MODE_FUSED);
+#undef LAUNCH1
 #undef LAUNCH
     return decnet_launch_status();
 }
