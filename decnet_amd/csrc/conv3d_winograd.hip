@@ -653,6 +653,41 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
     wino_gemm_wave<NFULL, TAIL, 3>(Vb, Ub, Mb, nt, Ci, Co, xg, np, pg * xg, (mb * WM + wm) * 48, wn, swz & 2);
 }
 
+// The same GEMM with the machine filled ONCE and the work shared out by hand (default for Ci = 216).
+// A point's GEMM is cut into wave tasks of 48 tiles x 112 co; with 216 points x 15 x 2 = 6480 equal tasks on
+// the 2048 wave slots (2 per SIMD) the launch above runs 3.16 "rounds" of tasks as 4: the last quarter of the
+// time 5 % of the work.  Here 512 workgroups of 4 waves stay for the whole launch; the waves of XCD x (workgroup
+// id mod 8, the dispatcher's round robin) own the points x, x + 8, ...: each takes floor(tasks / waves) whole
+// tasks, and what is left over is cut in three along M (16 tiles x 112 co, TM = 1) so that the last step takes
+// a third of a task's MFMAs instead of a whole one -- 3.5 task times instead of 4.  Static assignment: no atomics,
+// nothing to reset between launches, re-entrant; if fewer workgroups are resident (another stream shares the
+// GPU) the rest simply run afterwards.
+template <int NFULL, int TAIL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_persist(
+    const float *__restrict__ Vb, const float *__restrict__ Ub, float *__restrict__ Mb, int nt, int Ci,
+    int Co, int np) {
+    const int xcd = blockIdx.x & 7, wx = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    const int nwx = (gridDim.x >> 3) * 4;                           // waves per XCD
+    const int MB = (nt + 47) / 48, npx = (np - xcd + 7) >> 3;       // this XCD's points: xcd, xcd + 8, ...
+    const int tasks = npx * MB * 2, full = tasks / nwx, rem = tasks - full * nwx;
+    // task id -> (point, M block, co half); consecutive ids = the two co halves of one V block, then the next
+    // M block of the same point: the waves of an XCD share few points' U^T at any time
+    auto big = [&](int t) {
+        const int pl = t / (MB * 2), r = t - pl * (MB * 2);
+        wino_gemm_wave<NFULL, TAIL, 3>(Vb, Ub, Mb, nt, Ci, Co, 1, np, xcd + 8 * pl, (r >> 1) * 48, r & 1, 0);
+    };
+    for (int r = 0; r < full; ++r) big(r * nwx + wx);
+    if (3 * rem <= 2 * nwx) {                                       // thirds of the left-over tasks
+        for (int u = wx; u < 3 * rem; u += nwx) {
+            const int t = full * nwx + u / 3, part = u - (u / 3) * 3;
+            const int pl = t / (MB * 2), r = t - pl * (MB * 2);
+            wino_gemm_wave<NFULL, TAIL, 1>(Vb, Ub, Mb, nt, Ci, Co, 1, np, xcd + 8 * pl, (r >> 1) * 48 + part * 16, r & 1, 0);
+        }
+    } else if (wx < rem) {
+        big(full * nwx + wx);
+    }
+}
+
 // ------------------------------ the same GEMM on the bf16 matrix cores, fp32 accurate ------------
 // DECNET_WINO_GEMM=bf16x3 (experimental).  tools/ubench/mfma_rate.hip: v_mfma_f32_16x16x4_f32 issues
 // every ~35 cycles, v_mfma_f32_16x16x32_bf16 every ~18.  Each fp32 operand is split into three bf16
@@ -844,6 +879,11 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
         const int *Ub = reinterpret_cast<const int *>(U + (size_t)np * pad16(Ci) * W_BN);   // split copy behind U^T
         hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(nt, 96), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
                            Co, np, swz);
+        return decnet_launch_status();
+    }
+    static const int gemm_static = [] { const char *e = getenv("DECNET_WINO_GEMM"); return e && !strcmp(e, "static") ? 1 : 0; }();
+    if (!gemm_static && !tile_env && Ci == 216 && np >= 8) {
+        hipLaunchKernelGGL((wino_gemm_persist<13, 2>), dim3(512), dim3(256), 0, s, V, U, M, nt, Ci, Co, np);
         return decnet_launch_status();
     }
     return tile_env == 192 ? launch_gemm<4>(V, U, M, nt, Ci, Co, np, s)

