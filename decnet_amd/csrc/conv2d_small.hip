@@ -37,8 +37,10 @@ template <int CO, int K>
 __global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__restrict__ w,
                                                     const float *__restrict__ scale,
                                                     const float *__restrict__ shift, float *__restrict__ y,
-                                                    int Cout, int H, int W, int dil, int relu) {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, yy = blockIdx.y, b = blockIdx.z;
+                                                    int Cout, int H, int W, int dil, int relu, int nrows) {
+    int bx, row;
+    if (!decnet_xcd_rows((W + 1023) >> 10, nrows, bx, row)) return;      // rows of one XCD's blocks are neighbours
+    const int x0 = (bx * 256 + threadIdx.x) * 4, b = row / H, yy = row - b * H;
     if (x0 >= W) return;
     const size_t plane = (size_t)H * W;
     const int xl = x0 - (K / 2) * dil;                                   // first element of the left tap
@@ -230,13 +232,13 @@ __global__ __launch_bounds__(256) void bias_act_inplace(float *__restrict__ y, c
 template <int CO>
 int launch_conv(const Segs &in, const float *w, const float *scale, const float *shift, float *y, int B,
                 int Cout, int H, int W, int k, int dil, int relu, hipStream_t s) {
-    const dim3 grid((unsigned)ceil_div(W, 1024), (unsigned)H, (unsigned)B);
+    const dim3 grid(decnet_xcd_grid(ceil_div(W, 1024), (long)H * B));
     if (k == 3)
         hipLaunchKernelGGL((conv2d_small<CO, 3>), grid, dim3(256), 0, s, in, w, scale, shift, y, Cout, H, W, dil,
-                           relu);
+                           relu, H * B);
     else
         hipLaunchKernelGGL((conv2d_small<CO, 1>), grid, dim3(256), 0, s, in, w, scale, shift, y, Cout, H, W, dil,
-                           relu);
+                           relu, H * B);
     return decnet_launch_status();
 }
 
@@ -246,9 +248,11 @@ int launch_conv(const Segs &in, const float *w, const float *scale, const float 
 // differences, taps added in the order nw, ne, sw, se).
 __global__ __launch_bounds__(256) void warp_disparity(const float *__restrict__ right,
                                                       const float *__restrict__ disp, float *__restrict__ out,
-                                                      int C, int H, int W) {
+                                                      int C, int H, int W, int nrows) {
 #pragma clang fp contract(off)
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    int bx, row;
+    if (!decnet_xcd_rows((W + 255) >> 8, nrows, bx, row)) return;        // (two input rows per output row)
+    const int x = bx * 256 + threadIdx.x, b = row / H, y = row - b * H;
     if (x >= W) return;
     const size_t plane = (size_t)H * W;
     const float d = disp[(size_t)b * plane + (size_t)y * W + x];
@@ -388,8 +392,8 @@ int decnet_warp_disparity(const float *right, const float *disp, float *out, int
     if (!right || !disp || !out) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || C < 1 || H < 2 || W < 2) return DECNET_ERR_BAD_SHAPE;
     if (H > 65535 || B > 65535) return DECNET_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(warp_disparity, dim3((unsigned)ceil_div(W, 256), (unsigned)H, (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, right, disp, out, C, H, W);
+    hipLaunchKernelGGL(warp_disparity, dim3(decnet_xcd_grid(ceil_div(W, 256), (long)H * B)), dim3(256), 0,
+                       (hipStream_t)stream, right, disp, out, C, H, W, H * B);
     return decnet_launch_status();
 }
 

@@ -27,8 +27,10 @@ __global__ __launch_bounds__(256) void detail_mask(const float *__restrict__ cur
                                                    MaskGenParams P, float *__restrict__ mask,
                                                    float *__restrict__ logits,
                                                    unsigned long long *__restrict__ bits, int H, int W,
-                                                   int words_per_row) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+                                                   int words_per_row, int nrows) {
+    int bx, row;
+    if (!decnet_xcd_rows((W + 255) >> 8, nrows, bx, row)) return;        // a 3-row stencil: rows of one XCD are neighbours
+    const int x = bx * 256 + threadIdx.x, b = row / H, y = row - b * H;
     const size_t plane = (size_t)H * W;
     const float *c0 = cur + (size_t)b * 3 * plane, *p0 = pre + (size_t)b * 3 * plane;
     float t[3] = {0.f, 0.f, 0.f};
@@ -83,7 +85,7 @@ extern "C" int decnet_detail_mask(const float *cur3, const float *pre3, const fl
     for (int i = 0; i < 3; ++i) { P.scale3[i] = scale3[i]; P.shift3[i] = shift3[i]; P.w1[i] = w1x1[i]; }
     P.scale1 = scale1; P.shift1 = shift1; P.thold = thold;
     const int wpr = (W + 63) / 64;
-    hipLaunchKernelGGL(detail_mask, dim3((unsigned)ceil_div(W, 256), (unsigned)H, (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, cur3, pre3, P, mask, logits, bits, H, W, wpr);
+    hipLaunchKernelGGL(detail_mask, dim3(decnet_xcd_grid(ceil_div(W, 256), (long)H * B)), dim3(256), 0,
+                       (hipStream_t)stream, cur3, pre3, P, mask, logits, bits, H, W, wpr, H * B);
     return decnet_launch_status();
 }

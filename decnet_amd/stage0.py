@@ -165,6 +165,14 @@ class CostRegNetNoDown(nn.Module):
     def units(self):
         return list(self.conv0) + list(self.conv1) + list(self.conv2)
 
+    def _replicate_for_data_parallel(self):
+        # torch.nn.DataParallel (eval.py:145-146) shallow-copies __dict__ per replica: the packed weights may be
+        # shared (they are keyed by the parameters' pointers and versions), the scratch buffers may not -- replicas
+        # run on worker threads at the same time
+        r = super()._replicate_for_data_parallel()
+        r._ws = {}
+        return r
+
     # ---- parameter preparation (once per weight version): repack + BN folding -----------
     def _key(self):
         k = []

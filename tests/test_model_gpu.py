@@ -141,7 +141,7 @@ def test_data_parallel_replicas_share_nothing_mutable():
         want = [model(left, right)[-1].clone(), model(left2, right2)[-1].clone()]
         reps = replicate(model, [0, 0])
         assert reps[0].cost_regularizer is not model.cost_regularizer
-        assert reps[0].cost_regularizer.conv0[0].conv.weight.data_ptr() != model.cost_regularizer.conv0[0].conv.weight.data_ptr()
+        assert reps[0].cost_regularizer._ws is not reps[1].cost_regularizer._ws      # scratch is per replica
         got = parallel_apply(reps, [(left, right), (left2, right2)])
     for w, g in zip(want, got):
         assert float((w - g[-1]).abs().max()) < 1e-4
