@@ -1047,7 +1047,8 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     // dense rows on the bf16 matrix cores (dense16_body) for the shipped channel counts (C = 8, 24) unless
     // DECNET_SPAMAT_DENSE=fp32 or the compaction paths are pinned off; it needs more LDS per staged position
     static const int dense_fp32 = [] { const char *e = getenv("DECNET_SPAMAT_DENSE"); return e && !strcmp(e, "fp32"); }();
-    const bool d16 = KQ == 2 && !dense_fp32;          // C = 24: three channel groups to split, measured slower (0.084 vs 0.063 ms)
+    // (C = 24, three channel groups to split per staged position: 0.080 vs 0.062 ms at stage 2 -- stays on fp32 MFMA)
+    const bool d16 = KQ == 2 && !dense_fp32;
     auto bytes = [&](int xt) { return (size_t)4 * make_layout(C, NT, xt, d16).total; };
     // whole row per workgroup when two workgroups (16 waves) still fit a CU's LDS; otherwise
     // equal segments that do; otherwise whatever fits once.  Segments hold <= 64 tiles so that
