@@ -503,11 +503,12 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t rsrc, int voff)
 }
 
 // One wave's work: TM x 7 MFMA tiles (16*TM tiles m from m0, 112 co) of the xg points from xi0.
-template <int NFULL, int TAIL, int TM>
+// (TN x J0: the co tiles J0 .. J0+TN-1 of the wave's 112-co half; 7 x 0 = all of it)
+template <int NFULL, int TAIL, int TM, int TN = 7, int J0 = 0>
 __device__ __forceinline__ void wino_gemm_wave(const float *__restrict__ Vb, const float *__restrict__ Ub,
                                                float *__restrict__ Mb, int nt, int Ci, int Co, int xg,
                                                int np, int xi0, int m0, int wn, int v_shared) {
-    constexpr int TN = 7, OOB = 0x7fffffff;
+    constexpr int OOB = 0x7fffffff;
     const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
     if (m0 >= nt) return;                               // no barriers: idle waves of the M tail just leave
     const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;
@@ -525,7 +526,7 @@ __device__ __forceinline__ void wino_gemm_wave(const float *__restrict__ Vb, con
         v_row[i] = m < nt ? m * 64 : OOB;
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) u_row[j] = (wn * (W_BN / 2) + j * 16 + i16) * 64;
+    for (int j = 0; j < TN; ++j) u_row[j] = (wn * (W_BN / 2) + (J0 + j) * 16 + i16) * 64;
 
     f32x4 v0[TM], u0[TN], v1[TM], u1[TN];
     // (p, c) = point (relative) and chunk; beyond the last point the offsets go out of range: zeros, no traffic
@@ -574,7 +575,7 @@ __device__ __forceinline__ void wino_gemm_wave(const float *__restrict__ Vb, con
 #endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int cg = wn * TN + j;                 // 16-co group: rows 4kq + r of MFMA tile j
+            const int cg = wn * 7 + J0 + j;             // 16-co group: rows 4kq + r of MFMA tile j
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const f32x4 a = acc[j][i];
@@ -677,7 +678,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wino_gemm_wave<NFULL, TAIL, 3>(Vb, Ub, Mb, nt, Ci, Co, 1, np, xcd + 8 * pl, (r >> 1) * 48, r & 1, 0);
     };
     for (int r = 0; r < full; ++r) big(r * nwx + wx);
-    if (3 * rem <= 2 * nwx) {                                       // thirds of the left-over tasks
+    if (6 * rem <= nwx + nwx / 4) {                                 // sixths: thirds along M x (4 | 3 co tiles)
+        for (int u = wx; u < 6 * rem; u += nwx) {
+            const int t = full * nwx + u / 6, part = (u % 6) >> 1, half = u & 1;
+            const int pl = t / (MB * 2), r = t - pl * (MB * 2);
+            if (half == 0)
+                wino_gemm_wave<NFULL, TAIL, 1, 4, 0>(Vb, Ub, Mb, nt, Ci, Co, 1, np, xcd + 8 * pl, (r >> 1) * 48 + part * 16, r & 1, 0);
+            else
+                wino_gemm_wave<NFULL, TAIL, 1, 3, 4>(Vb, Ub, Mb, nt, Ci, Co, 1, np, xcd + 8 * pl, (r >> 1) * 48 + part * 16, r & 1, 0);
+        }
+    } else if (3 * rem <= 2 * nwx) {                                // thirds of the left-over tasks
         for (int u = wx; u < 3 * rem; u += nwx) {
             const int t = full * nwx + u / 3, part = u - (u / 3) * 3;
             const int pl = t / (MB * 2), r = t - pl * (MB * 2);
