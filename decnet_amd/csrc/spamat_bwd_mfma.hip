@@ -48,13 +48,15 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, in
 struct BLayout {
     int SW, HALO, OW, OP, Cq, offP, total;
 };
-__host__ __device__ inline BLayout make_blayout(int C, int NT, int XT, int npl) {
+// cq: channel rows staged = 4 * KQ of the instantiation (>= C): the cost MFMAs read all of them (against zero own
+// operands beyond C), so the rows between C and 4 KQ must exist and hold zeros, not whatever LDS held before
+__host__ __device__ inline BLayout make_blayout(int cq, int NT, int XT, int npl) {
     BLayout l;
     l.SW = XT * 16;
     l.HALO = (NT - 1) * 16;
     l.OW = l.HALO + l.SW;                       // staged other-side pixels (multiple of 16)
     l.OP = ((l.OW + 63) & ~63) + 4;
-    l.Cq = (C + 3) & ~3;
+    l.Cq = cq;
     l.offP = l.Cq * l.OP;
     l.total = l.offP + npl * l.OW;
     return l;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
     constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
     constexpr int NCB = (4 * KQ + 15) / 16;          // 16-channel blocks of the contraction
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const BLayout lo = make_blayout(C, NT, XT, NPL);
+    const BLayout lo = make_blayout(4 * KQ, NT, XT, NPL);
     float *Os = smem;
     float *PL = smem + lo.offP;
     const int SW = lo.SW, HALO = lo.HALO, OW = lo.OW, OP = lo.OP;
@@ -101,17 +103,41 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
         const bool alp = (rowpix & 3) == 0 && ((((uintptr_t)oth_mask) | ((uintptr_t)out) |
                                                 ((uintptr_t)sum_sim) | ((uintptr_t)max_cost) |
                                                 ((uintptr_t)grad_out)) & 15) == 0;
+        // features: threads spread over (channel row, group of 4 positions), up to 8 loads in flight each
+        // (stage 1, C = 72 over 144 positions: 6 loads per thread instead of 72 serial ones on 36 threads)
+        const int nq = OW >> 2;
+        if (nq <= THREADS) {
+            const int rpp = THREADS / nq, r0 = tid / nq, jq = tid - r0 * nq;
+            if (r0 < rpp) {
+                const int jj = 4 * jq, x = xo0 + jj;
+                for (int c0 = r0; c0 < lo.Cq; c0 += 8 * rpp) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + u * rpp;
+                        v[u] = c < C ? load4(oth_row + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + u * rpp;
+                        if (c < lo.Cq) *reinterpret_cast<float4 *>(Os + c * OP + jj) = v[u];
+                    }
+                }
+            }
+        }
         for (int j = tid * 4; j < OW; j += THREADS * 4) {
             const int x = xo0 + j;
-            for (int c0 = 0; c0 < lo.Cq; c0 += 8) {
-                float4 v[8];
+            if (nq > THREADS) {
+                for (int c0 = 0; c0 < lo.Cq; c0 += 8) {
+                    float4 v[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    v[c] = c0 + c < C ? load4(oth_row + (size_t)(c0 + c) * plane, x, W, al)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int c = 0; c < 8; ++c)
+                        v[c] = c0 + c < C ? load4(oth_row + (size_t)(c0 + c) * plane, x, W, al)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if (c0 + c < lo.Cq) *reinterpret_cast<float4 *>(Os + (c0 + c) * OP + j) = v[c];
+                    for (int c = 0; c < 8; ++c)
+                        if (c0 + c < lo.Cq) *reinterpret_cast<float4 *>(Os + (c0 + c) * OP + j) = v[c];
+                }
             }
             const float4 mk = load4(oth_mask, x, W, alp);
             const bool on[4] = {x >= 0 && x < W && mk.x != 0.f, x + 1 >= 0 && x + 1 < W && mk.y != 0.f,
@@ -273,10 +299,10 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
 
 // tiles per segment of the band kernel for one side (0 = does not fit)
 template <int NT, bool VAR, int SIDE>
-int side_xt(int C, int W) {
+int side_xt(int cq, int W) {
     constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
     const int xt_row = ceil_div(W, 16);
-    auto bytes = [&](int xt) { return (size_t)4 * make_blayout(C, NT, xt, NPL).total; };
+    auto bytes = [&](int xt) { return (size_t)4 * make_blayout(cq, NT, xt, NPL).total; };
     const size_t budget2 = (DECNET_LDS_BYTES - 2048) / 2, budget1 = DECNET_LDS_BYTES - 1024;
     int XT = xt_row;
     if (bytes(XT) > budget2) {
@@ -297,7 +323,7 @@ int launch_side(const float *ref, const float *tar, const float *rmask, const fl
                 const float *grad_out, float *grad_own, float *grad_disp, int B, int C, int H, int W,
                 int D, int XT, int marker, hipStream_t stream) {
     constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
-    const size_t lds = (size_t)4 * make_blayout(C, NT, XT, NPL).total;
+    const size_t lds = (size_t)4 * make_blayout(4 * KQ, NT, XT, NPL).total;
     const int segs = ceil_div(ceil_div(W, 16), XT);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)spamat_bwd_mfma<NT, VAR, KQ, SIDE>,
@@ -578,7 +604,7 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
                 const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
                 const float *grad_out, float *grad_ref, float *grad_tar, float *grad_disp, int B, int C,
                 int H, int W, int D, hipStream_t stream) {
-    const int xt0 = side_xt<NT, VAR, 0>(C, W), xt1 = side_xt<NT, VAR, 1>(C, W);
+    const int xt0 = side_xt<NT, VAR, 0>(4 * KQ, W), xt1 = side_xt<NT, VAR, 1>(4 * KQ, W);
     if (!xt0 || !xt1) return DECNET_ERR_UNSUPPORTED;
     // sparse rows first (C <= 24, rows of <= 2048 pixels), the rest by the marker launches
     static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
