@@ -464,7 +464,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int XT, int allow_compact, int marker, int seg, int row) {
+    int H, int W, int D, int XT, int allow_compact, int marker, int seg, int row, int compact_pct) {
     // marker: this launch follows spamat_fwd_sparse, which left -1 in sum_sim[row start] of exactly
     // the rows it did not take, at the first pixel of every segment (a real sum_similarities is never
     // negative)
@@ -531,7 +531,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
         for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
         const int validL = min(SW, W - xs);
         const int validR = min(W, xs + SW) - max(0, xs - HALO);
-        compact = allow_compact && ((long)nL * nR * 5 < (long)validL * validR * 4);
+        compact = allow_compact && ((long)nL * nR * 100 < (long)validL * validR * compact_pct);
         if (!compact) {
             // two passes over half the segment each: both views as bf16 terms need 96 bytes of LDS per pixel and
             // channel group, and the segment partition (= the number of workgroups of a marker launch, the
@@ -587,7 +587,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
 #pragma unroll
         for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
         // compact when fewer than 80 % of the candidate pairs are active (block-uniform)
-        compact = allow_compact && ((long)nL * nR * 5 < (long)validL * validR * 4);
+        compact = allow_compact && ((long)nL * nR * 100 < (long)validL * validR * compact_pct);
     }
 
     const int j = lane & 15, q = lane >> 4;
@@ -822,10 +822,10 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker) {
+    int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker, int compact_pct) {
     spamat_fwd_segment<NT, MODE, KQ, D16>(ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W,
                                           D, XT, allow_compact, marker, blockIdx.x % segs_per_row,
-                                          blockIdx.x / segs_per_row);
+                                          blockIdx.x / segs_per_row, compact_pct);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int seg_w) {
+    int H, int W, int D, int seg_w, int dense_pct) {
     // at most 8 cost tiles per span (32 accumulator registers: six workgroups per CU); a row whose
     // disparity windows hold more than 8*16-15 active right pixels even for 16-pixel spans goes to
     // spamat_fwd_mfma like the dense ones
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     auto hand_over = [&]() {                           // left to spamat_fwd_mfma (marker launch)
         for (int x = tid * seg_w; x < W; x += SP_THREADS * seg_w) sum_sim[rowpix + x] = -1.0f;
     };
-    if (nL > SP_CAP || nR > SP_CAP || (long)nL * nR * 5 >= (long)W * W * 4) {
+    if (nL > SP_CAP || nR > SP_CAP || (long)nL * nR * 100 >= (long)W * W * dense_pct) {
         hand_over();
         return;
     }
@@ -1070,10 +1070,16 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     if (lds > budget1 || make_layout(C, NT, XT, d16).RP > 2048) return DECNET_ERR_UNSUPPORTED;
     const int segs = ceil_div(xt_row, XT);
     dim3 block(THREADS);
+    // rows go through the compaction path when fewer than compact_pct % of their candidate pairs are active
+    // (DECNET_SPAMAT_COMPACT_PCT; 80 in round 1 -- but the dense path is faster down to ~35 %, measured)
+    static const int compact_pct = [] { const char *e = getenv("DECNET_SPAMAT_COMPACT_PCT"); return e ? atoi(e) : 35; }();
+    dim3 grid((unsigned)((size_t)B * H * segs));
     // sparse rows first (KQ > 0: C <= 24; rows of <= 2048 pixels), the rest by the marker launch
     static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
-    const int marker = allow_compact && !sparse_off && KQ > 0 && KQ <= 6 && W <= 2048;
-    dim3 grid((unsigned)((size_t)B * H * segs));
+    // (C = 24, stage 2: rows are short and in practice 40-100 % dense -- there the sparse-row pre-launch costs 6 us
+    // of a 57 us pass and only wins below ~20 % density; DECNET_SPAMAT_SPARSE=2 switches it on for C <= 24 too)
+    static const int sparse_c24 = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 2; }();
+    const int marker = allow_compact && !sparse_off && (KQ == 2 || (KQ == 6 && sparse_c24)) && W <= 2048;
     if constexpr (KQ > 0 && KQ <= 6) if (marker) {
         const int ppt = W <= 1024 ? 4 : 8;
         const size_t slds = 4 * (size_t)(SP_CAP + 16 + 2 * (SP_THREADS * ppt / 2 + 2) + SP_CAP + 16 +
@@ -1087,7 +1093,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_sparse<NT, M, (KQ ? KQ : 1), P>), dim3((unsigned)(B * H)),  \
                            dim3(SP_THREADS), slds, stream, ref, tar, rmask, tmask, disparity, out, \
-                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16);                       \
+                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16, compact_pct);          \
     } while (0)
 #define LAUNCHSP(M)                                                                                \
     do {                                                                                           \
@@ -1111,7 +1117,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ, DD>), grid, block, lds, stream, ref, tar, rmask, \
                            tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT, \
-                           allow_compact, marker);                                                 \
+                           allow_compact, marker, compact_pct);                                    \
     } while (0)
 #define LAUNCH(M)                                                                                  \
     do {                                                                                           \
