@@ -467,6 +467,13 @@ def main_train(args, B, dev, world, rank):
     ts = TrainShare(B, dev, args.mask_density, world)
     with torch.no_grad():
         elapsed = timed_region(ts.step, ts.drain, args.warmup, args.steps, world, dev)
+        t_ar = None
+        if world > 1:                                    # the gradient all-reduce alone, not overlapped: a
+            def ar():                                    # collective, so EVERY rank runs it (outside the timed region)
+                for i in range(len(ts.grads)):
+                    ts.grads.reduce_async(i)
+                ts.grads.wait()
+            t_ar = time_kernel(ar, 10, warm=3)
         if rank == 0:
             ms_step = 1e3 * elapsed / args.steps
             C, H, W, D = STAGES[3]
@@ -475,13 +482,6 @@ def main_train(args, B, dev, world, rank):
                                                             b["gr"], D), 30)
             tf = time_kernel(lambda: ts.ops.spamat_forward(L, R, rm, tm, b["o"], b["ss"], b["mc"], D), 30)
             nb = 4.0 * B * H * W * (4 * C + 6)
-            t_ar = None
-            if world > 1:                                # the gradient all-reduce alone, not overlapped
-                def ar():
-                    for i in range(len(ts.grads)):
-                        ts.grads.reduce_async(i)
-                    ts.grads.wait()
-                t_ar = time_kernel(ar, 10, warm=3)
             traffic = {}
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
