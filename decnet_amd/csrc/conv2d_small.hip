@@ -343,7 +343,8 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
                        int Cout, int H, int W, int k, int dilation, int relu, void *stream) {
     if (!w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
-    if ((k != 1 && k != 3) || Cout > 24 || H > 65535 || B > 65535 || W > (1 << 28)) return DECNET_ERR_UNSUPPORTED;
+    if ((k != 1 && k != 3) || Cout > 24 || H > 65535 || B > 65535 || W > (1 << 28) ||
+        (double)B * H * ceil_div(W, 1024) >= 2.0e9) return DECNET_ERR_UNSUPPORTED;
     int cin = 0;
     for (int i = 0; i < in.n; ++i) {
         if (!in.p[i]) return DECNET_ERR_NULL_POINTER;
@@ -391,7 +392,7 @@ int decnet_warp_disparity(const float *right, const float *disp, float *out, int
                           void *stream) {
     if (!right || !disp || !out) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || C < 1 || H < 2 || W < 2) return DECNET_ERR_BAD_SHAPE;
-    if (H > 65535 || B > 65535) return DECNET_ERR_UNSUPPORTED;
+    if (H > 65535 || B > 65535 || (double)B * H * ceil_div(W, 256) >= 2.0e9) return DECNET_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(warp_disparity, dim3(decnet_xcd_grid(ceil_div(W, 256), (long)H * B)), dim3(256), 0,
                        (hipStream_t)stream, right, disp, out, C, H, W, H * B);
     return decnet_launch_status();

@@ -80,6 +80,7 @@ extern "C" int decnet_detail_mask(const float *cur3, const float *pre3, const fl
                                   int H, int W, void *stream) {
     if (!cur3 || !pre3 || !w3x3 || !scale3 || !shift3 || !w1x1 || !mask) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || H < 1 || W < 1 || B > 65535 || H > 65535) return DECNET_ERR_BAD_SHAPE;
+    if ((double)B * H * ceil_div(W, 256) >= 2.0e9) return DECNET_ERR_UNSUPPORTED;
     MaskGenParams P;                       // host arrays: 90 floats, passed by value as a kernel argument
     for (int i = 0; i < 81; ++i) (&P.w3[0][0][0][0])[i] = w3x3[i];
     for (int i = 0; i < 3; ++i) { P.scale3[i] = scale3[i]; P.shift3[i] = shift3[i]; P.w1[i] = w1x1[i]; }
