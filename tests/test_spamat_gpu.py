@@ -332,3 +332,24 @@ def test_shapes_beyond_any_lds_tile(dev, B, C, H, W, D, p):
     assert np.abs(dL.grad.cpu().numpy() - gl).max() < 6e-5 * sc
     assert np.abs(dR.grad.cpu().numpy() - gr).max() < 6e-5 * sc
     assert np.abs(dmu.grad.cpu().numpy() - gd).max() < 6e-5 * sc
+
+
+@pytest.mark.parametrize("C,W,D,scale,relu", [(8, 500, 216, 12.0, True), (8, 400, 216, 6.0, False), (24, 324, 72, 8.0, True),
+                                              (8, 972, 216, 1e-3, True)])
+def test_large_and_small_magnitudes(dev, C, W, D, scale, relu):
+    """Costs of ~1e3 (features x 12: the exponent arguments reach -1e3 and most candidates underflow to 0, as in
+    the reference) and of ~1e-5 (every candidate at the 1e-6 floor of max_cost, SM_kernel.cu:45): no overflow, no
+    NaN, same soft-argmax.  Dense rows (bf16x3 cost tiles at C = 8) and sparse rows."""
+    import decnet_amd
+    for dens in (1.0, 0.15):
+        L, R, rm, tm = make_case(77, 1, C, 3, W, dens, dens, relu=relu, scale=scale)
+        o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+        fo, fv, fs, fm = decnet_amd.spamatvar_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
+        for t in (fo, fv, fs, fm):
+            assert bool(torch.isfinite(t).all())
+        np.testing.assert_allclose(fm.cpu().numpy(), m, rtol=2e-5, atol=1e-7)
+        # a sharp softmax amplifies cost rounding by the cost scale: disparities agree where the maximum is
+        # separated, and on average
+        err = np.abs(fo.cpu().numpy() - o)
+        assert np.median(err) < 1e-4 and err.mean() < (2e-3 if scale > 1 else 1e-4), (dens, err.mean(), err.max())
+        np.testing.assert_allclose(fs.cpu().numpy(), s, rtol=2e-3 if scale > 1 else 2e-5, atol=1e-9)
