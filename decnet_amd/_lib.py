@@ -40,6 +40,9 @@ SIGNATURES = {
     "decnet_unfold3_cat": [_P] * 3 + [_I] * 4 + [_P],
     "decnet_detail_mask": [_P] * 6 + [_F] * 3 + [_P] * 3 + [_I] * 3 + [_P],
     "decnet_conv2d_cat_bn_act": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P],
+    "decnet_conv2d_mfma_packed_bytes": [_I] * 3,
+    "decnet_conv2d_mfma_pack_weight": [_P, _P] + [_I] * 3 + [_P],
+    "decnet_conv2d_mfma_cat_bn_act": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P],
     "decnet_warp_disparity": [_P, _P, _P] + [_I] * 4 + [_P],
     "decnet_dynamic_upsample3": [_P, _P, _P] + [_I] * 3 + [_P],
     "decnet_tapconv_chunk_floats": [_I] * 4,
@@ -86,7 +89,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)
             fn.argtypes = args
-            fn.restype = ctypes.c_size_t if name.endswith("_floats") else _I
+            fn.restype = ctypes.c_size_t if name.endswith(("_floats", "_bytes")) else _I
         h.decnet_version.restype = ctypes.c_char_p
         h.decnet_version.argtypes = []
         _lib = h

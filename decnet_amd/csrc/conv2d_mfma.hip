@@ -1,0 +1,375 @@
+// decnet_amd/csrc/conv2d_mfma.hip -- the many-channel Conv2dUnit layers of the 2-D trunk on the matrix cores.
+//
+// Replaces (eval mode) the library convolution behind
+//   * FeatureExtraction conv1.* / conv2.* / conv3_2.* and the Deconv2dBlock convs   submodule.py:245-343, 162-178
+//   * DynamicUpsampling.weight_learning (73/217/649 -> 81 -> 81 -> 81)               submodule.py:566-589
+//   * Refinement convs at 24..72 channels                                            submodule.py:690-717
+// i.e. Conv2d k = 3 (any dilation, padding = dilation) or k = 1, stride 1, followed by the folded BatchNorm and
+// ReLU of Conv2dUnit.forward (submodule.py:15-45), optionally on the channel concatenation of up to six tensors.
+//
+// Arithmetic: implicit GEMM  Y[pixel][co] = sum_tap sum_ci X[pixel + tap][ci] * Wt[tap][ci][co]  on
+// v_mfma_f32_16x16x32_bf16 at fp32 accuracy: every fp32 operand is split into three bf16 terms
+// x = hi + mid + lo (truncations with exact residuals, 24 mantissa bits together) and the six products above 2^-24
+// (hi.hi hi.mid mid.hi mid.mid hi.lo lo.hi) go into the K axis of three MFMAs per 16 input channels:
+//   j = 0 / 1 : channels 0-7 / 8-15,  A k-groups {hi,hi,mid,mid} x B k-groups {hi,mid,hi,mid}
+//   j = 2     : A {hi(0-7), lo(0-7), hi(8-15), lo(8-15)} x B {lo(0-7), hi(0-7), lo(8-15), hi(8-15)}
+// against 4 x v_mfma_f32_16x16x4_f32 of 32 cycles each for the same 16 channels: 3 x 16 cycles.
+//
+// Tiling: a 256-thread workgroup owns 4 TM rows x 16 columns of output pixels x (up to) TN x 16 output channels; wave
+// w owns rows w TM .. w TM + TM - 1, one 16-pixel MFMA tile per row, TM x TN accumulator tiles.  Per 16-channel
+// chunk the input halo tile is split once into its bf16 terms and kept in LDS as [term][8-channel group][pixel][8 x
+// bf16] (one ds_read_b128 per lane = one A operand, conflict free); the weights are split at packing time and
+// streamed from L2 as ready-made B operands (one 16-byte load per lane), each used for TM MFMAs.
+// Epilogue: relu(acc * scale + shift) -> NCHW, 64-byte runs per (channel, row).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef DECNET_C2M_ABLATE
+#define DECNET_C2M_ABLATE 0      // timing experiments only: 1 stage chunk 0 only, 2 never advance the weight pointer
+#endif
+
+namespace {
+
+constexpr int MAXSEG = 6;
+constexpr int THREADS = 256;
+
+struct Segs {
+    const float *p[MAXSEG];
+    int c[MAXSEG];
+    int n;
+};
+
+// output-channel tiles (of 16) per workgroup, and the padded tile count of a layer
+__host__ __device__ inline int pick_tn(int Cout) {
+    const int nt = (Cout + 15) >> 4;
+    return nt <= 2 ? 2 : nt <= 3 ? 3 : nt == 4 ? 4 : nt <= 6 ? nt : 5;
+}
+__host__ __device__ inline int padded_nt(int Cout) {
+    const int tn = pick_tn(Cout), nt = (Cout + 15) >> 4;
+    return (nt + tn - 1) / tn * tn;
+}
+
+__device__ __forceinline__ void split3(float x, int &h, int &m, int &l) {
+    h = __float_as_int(x) & 0xffff0000;
+    const float r1 = x - __int_as_float(h);
+    m = __float_as_int(r1) & 0xffff0000;
+    l = __float_as_int(r1 - __int_as_float(m));
+}
+
+// w [Cout][Cin][KT] -> wp[chunk][tap][j][n tile][lane] (16 bytes: the lane's 8 bf16 of the B operand)
+__global__ void conv2d_mfma_pack(const float *__restrict__ w, i32x4 *__restrict__ wp, int Cin, int Cout, int KT,
+                                 int NT, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    long rest = idx >> 6;
+    const int nt = (int)(rest % NT); rest /= NT;
+    const int j = (int)(rest % 3); rest /= 3;
+    const int tap = (int)(rest % KT);
+    const int ck = (int)(rest / KT);
+    const int n = nt * 16 + (lane & 15), b = lane >> 4;
+    const int term = j < 2 ? (b & 1) : ((b & 1) ? 0 : 2);
+    const int grp = j < 2 ? j : (b >> 1);
+    int t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 16 * ck + 8 * grp + e;
+        const float v = (n < Cout && c < Cin) ? w[((size_t)n * Cin + c) * KT + tap] : 0.f;
+        int h, m, l;
+        split3(v, h, m, l);
+        t[e] = term == 0 ? h : term == 1 ? m : l;
+    }
+    i32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_perm(t[2 * e + 1], t[2 * e], 0x07060302);
+    wp[idx] = o;
+}
+
+// NU: staging units per thread, 128 NU >= pixels of the halo tile
+template <int TM, int TN, int NU>
+__global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
+    Segs in, const i32x4 *__restrict__ wp, const float *__restrict__ scale, const float *__restrict__ shift,
+    float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x) {
+    constexpr int TH = 4 * TM;
+    extern __shared__ i32x4 smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pad = KT == 9 ? dil : 0;
+    const int PW = 16 + 2 * pad, PH = TH + 2 * pad, P = PW * PH;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int y0 = tyi * TH, x0 = txi * 16;
+    const int nt0 = blockIdx.y * TN;
+    const int b = blockIdx.z;
+    const size_t HW = (size_t)H * W;
+
+    const int r = lane & 15, q = lane >> 4;
+    // A operand of MFMA j: this lane's (term, channel group) plane of the LDS tile
+    int offA[3];
+    offA[0] = ((q >> 1) * 2 + 0) * P + r;
+    offA[1] = ((q >> 1) * 2 + 1) * P + r;
+    offA[2] = (((q & 1) ? 2 : 0) * 2 + (q >> 1)) * P + r;
+    const int rowbase = wave * TM;
+    const bool wave_active = y0 + rowbase < H;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const i32x4 *wb = wp + (size_t)nt0 * 64 + lane;          // advances NT * 64 per (chunk, tap, j)
+    const int wstep = NT * 64;
+    i32x4 bq[TN];                                              // B operands of the current step
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) bq[nt] = wb[nt * 64];
+
+    // ---- staging: waves 0-1 the channels 0-7 of a chunk, waves 2-3 the channels 8-15; a thread owns the pixels
+    // (tid & 127) + 128 u of the halo tile.  issue(): global loads of a chunk into registers; commit(): split + LDS
+    const int sg = wave >> 1;
+    int po[NU];                                                // pixel offset inside a channel plane, -1: zero
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int p = (tid & 127) + 128 * u;
+        const int py = p / PW, px = p - py * PW;
+        const int gy = y0 - pad + py, gx = x0 - pad + px;
+        po[u] = (p < P && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    }
+    float raw[NU][8];
+    auto issue = [&](int ck) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ck + 8 * sg + e;
+            const float *cp = nullptr;
+            int base = 0;
+#pragma unroll
+            for (int s = 0; s < MAXSEG; ++s) {
+                if (s < in.n) {
+                    if (c >= base && c < base + in.c[s]) cp = in.p[s] + ((size_t)b * in.c[s] + (c - base)) * HW;
+                    base += in.c[s];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                float v = 0.f;
+                if (cp != nullptr && po[u] >= 0) v = cp[po[u]];
+                raw[u][e] = v;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int p = (tid & 127) + 128 * u;
+            if (p >= P) break;
+            int h[8], m[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split3(raw[u][e], h[e], m[e], l[e]);
+            i32x4 th, tm, tl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                th[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302);
+                tm[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302);
+                tl[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302);
+            }
+            smem[(0 * 2 + sg) * P + p] = th;
+            smem[(1 * 2 + sg) * P + p] = tm;
+            smem[(2 * 2 + sg) * P + p] = tl;
+        }
+    };
+
+    issue(0);
+    commit();
+    __syncthreads();
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const bool more = ck + 1 < nchunk;
+        if (more && !(DECNET_C2M_ABLATE & 1)) issue(ck + 1);   // in flight during this chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave_active) {
+            // every operand tile is re-loaded for the NEXT (tap, j) step right behind its last MFMA of this one: the B
+            // tiles (L2 latency) have most of a step to arrive, the A tiles (LDS) the TM MFMAs of the last column
+            i32x4 a[TM];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) a[mt] = smem[offA[0] + rowbase * PW + mt * PW];
+            for (int tap = 0; tap < KT; ++tap) {
+                const int tn_ = tap + 1 < KT ? tap + 1 : 0;
+                const int tyn = KT == 9 ? tn_ / 3 : 0, txn = KT == 9 ? tn_ - 3 * tyn : 0;
+                const int ty = KT == 9 ? tap / 3 : 0, tx = KT == 9 ? tap - 3 * ty : 0;
+                const int tapoff = (rowbase + ty * dil) * PW + tx * dil;
+                const int tapoff_n = (rowbase + tyn * dil) * PW + txn * dil;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (!(DECNET_C2M_ABLATE & 2)) wb += wstep;     // the packed buffer ends with one block of padding
+                    const int nxt = j < 2 ? offA[j + 1] + tapoff : offA[0] + tapoff_n;
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt) {
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a[mt]), __builtin_bit_cast(bf16x8, bq[nt]), acc[mt][nt], 0, 0, 0);
+                            if (nt == TN - 1) a[mt] = smem[nxt + mt * PW];
+                        }
+                        bq[nt] = wb[nt * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                           // the tile has been read by every wave
+        if (more) {
+            if (!(DECNET_C2M_ABLATE & 1)) commit();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane holds output channel n = tile * 16 + r, pixels x0 + 4 q .. + 3 of each row ----
+    if (!wave_active) return;
+    const int xq = x0 + 4 * q;
+    const bool vec = (W & 3) == 0 && xq + 3 < W;
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int n = (nt0 + nt) * 16 + r;
+        if (n >= Cout) continue;
+        const float sc = scale[n], sh = shift[n];
+        float *yp = y + ((size_t)b * Cout + n) * HW;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int row = y0 + rowbase + mt;
+            if (row >= H) break;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = fmaf(v[i], sc, sh);
+                if (relu) v[i] = fmaxf(v[i], 0.f);
+            }
+            float *dst = yp + (size_t)row * W + xq;
+            if (vec) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xq + i < W) dst[i] = v[i];
+            }
+        }
+    }
+}
+
+// Rows per wave.  Workgroups run two per CU (512 slots); a launch costs (rounds of 512 workgroups) x (TM + a fixed
+// share for prologue, staging and epilogue), e.g. H = 180: TM = 5 gives 9 exact row tiles and 2.95 rounds at batch 8.
+inline int pick_tm(int B, int H, int W, int nchunkN, int tn, int pad) {
+    const char *env = getenv("DECNET_CONV2D_MFMA_TM");                     // tests / experiments: pin the tile height
+    const int forced = env ? atoi(env) : 0;
+    static const int cand[5] = {8, 6, 5, 4, 2};
+    int best = 2;
+    double best_cost = 1e30;
+    for (int i = 0; i < 5; ++i) {
+        const int tm = cand[i];
+        if (tm * tn > 36 && !(tm == 8 && tn <= 4)) continue;             // accumulators + operands within 256 registers
+        if (pad > 1 && tm > 4) continue;
+        if (forced == tm) return tm;
+        const double wgs = (double)ceil_div(W, 16) * ceil_div(H, 4 * tm) * B * nchunkN;
+        const double cost = ceil(wgs / 512.0) * (tm + 0.7);
+        if (cost < best_cost) { best_cost = cost; best = tm; }
+    }
+    return best;
+}
+
+template <int TM, int TN, int NU>
+int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shift, float *y, int B, int Cout, int H,
+           int W, int KT, int dil, int relu, int nchunk, int NT, hipStream_t stream) {
+    const int pad = KT == 9 ? dil : 0;
+    const size_t lds = (size_t)(16 + 2 * pad) * (4 * TM + 2 * pad) * 6 * 16;
+    static bool attr = false;                                  // idempotent; a race sets the same value twice
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)conv2d_mfma<TM, TN, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  DECNET_LDS_BYTES);
+        attr = true;
+    }
+    const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 4 * TM);
+    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(NT / TN), (unsigned)B);
+    hipLaunchKernelGGL((conv2d_mfma<TM, TN, NU>), grid, dim3(THREADS), lds, stream, in, wp, scale, shift, y, Cout, H, W,
+                       KT, dil, relu, nchunk, NT, tiles_x);
+    return decnet_launch_status();
+}
+
+// pixels of the halo tile of a TM variant
+inline int tile_pixels(int tm, int pad) { return (16 + 2 * pad) * (4 * tm + 2 * pad); }
+
+template <int TN>
+int launch_tm(int tm, const Segs &in, const i32x4 *wp, const float *scale, const float *shift, float *y, int B,
+              int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, hipStream_t stream) {
+    const int pad = KT == 9 ? dil : 0;
+#define ARGS in, wp, scale, shift, y, B, Cout, H, W, KT, dil, relu, nchunk, NT, stream
+    if (pad <= 1) {
+        if constexpr (TN <= 4) {
+            if (tm == 8) return launch<8, TN, 5>(ARGS);
+        }
+        if (tm == 6) return launch<6, TN, 4>(ARGS);
+        if (tm == 5) return launch<5, TN, 4>(ARGS);
+        if (tm == 4) return launch<4, TN, 3>(ARGS);
+        return launch<2, TN, 2>(ARGS);
+    }
+    // dilated taps: bigger halo, 5 staging units per thread (640 pixels)
+    if (tm >= 4 && tile_pixels(4, pad) <= 640) return launch<4, TN, 5>(ARGS);
+    if (tile_pixels(2, pad) <= 640) return launch<2, TN, 5>(ARGS);
+#undef ARGS
+    return DECNET_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t decnet_conv2d_mfma_packed_bytes(int Cin, int Cout, int k) {
+    if (Cin < 1 || Cout < 1 || (k != 1 && k != 3)) return 0;
+    const size_t blocks = (size_t)ceil_div(Cin, 16) * (k * k) * 3 + 1;       // + 1: the prefetch runs one block ahead
+    return blocks * padded_nt(Cout) * 64 * 16;
+}
+
+int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream) {
+    if (!w || !w_packed) return DECNET_ERR_NULL_POINTER;
+    const size_t bytes = decnet_conv2d_mfma_packed_bytes(Cin, Cout, k);
+    if (!bytes) return DECNET_ERR_UNSUPPORTED;
+    const int NT = padded_nt(Cout);
+    const long total = (long)ceil_div(Cin, 16) * (k * k) * 3 * NT * 64;
+    hipError_t e = hipMemsetAsync((char *)w_packed + (size_t)total * 16, 0, bytes - (size_t)total * 16,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv2d_mfma_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (i32x4 *)w_packed, Cin, Cout, k * k, NT, total);
+    return decnet_launch_status();
+}
+
+int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int nseg, const void *w_packed,
+                                  const float *scale, const float *shift, float *y, int B, int Cout, int H, int W,
+                                  int k, int dilation, int relu, void *stream) {
+    if (!xs || !cins || !w_packed || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
+    if (nseg < 1 || nseg > MAXSEG || (k != 1 && k != 3)) return DECNET_ERR_UNSUPPORTED;
+    if (B < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
+    Segs in{};
+    long Cin = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!xs[i]) return DECNET_ERR_NULL_POINTER;
+        if (cins[i] < 1) return DECNET_ERR_BAD_SHAPE;
+        in.p[i] = xs[i];
+        in.c[i] = cins[i];
+        Cin += cins[i];
+    }
+    in.n = nseg;
+    if (B > 65535 || Cin > 65536 || (double)H * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;
+    const int TN = pick_tn(Cout), NT = padded_nt(Cout), nchunk = ceil_div((int)Cin, 16);
+    if (NT / TN > 65535 || (double)ceil_div(W, 16) * ceil_div(H, 8) >= 2.0e9) return DECNET_ERR_UNSUPPORTED;
+    const int tm = pick_tm(B, H, W, NT / TN, TN, k == 3 ? dilation : 0);
+    const i32x4 *wp = (const i32x4 *)w_packed;
+    hipStream_t st = (hipStream_t)stream;
+#define GO(T) case T: return launch_tm<T>(tm, in, wp, scale, shift, y, B, Cout, H, W, k * k, dilation, relu, nchunk, NT, st)
+    switch (TN) {
+        GO(2); GO(3); GO(4); GO(5); GO(6);
+    }
+#undef GO
+    return DECNET_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -47,12 +47,19 @@ class Unit(nn.Module):
                                   or t.device != x[0].device for t in x)):
                 return None
             kind = self._hip_kind(x[0])
-            return kind if kind == "conv" else None
+            return kind if kind in ("conv", "mfma") else None
         if self.training or not x.is_cuda or x.dtype != torch.float32 or torch.is_grad_enabled():
             return None
         if os.environ.get("DECNET_CONV2D", "hip") != "hip":
             return None
         c = self.conv
+        # many channels: the bf16x3 matrix-core kernel (csrc/conv2d_mfma.hip) where the image gives it enough
+        # workgroups (>= 60 x 108; below that the library's kernels win)
+        if (isinstance(c, nn.Conv2d) and c.out_channels >= 24 and c.in_channels >= 16 and c.kernel_size in ((1, 1), (3, 3)) and
+                c.stride == (1, 1) and c.dilation[0] == c.dilation[1] and c.groups == 1 and c.padding_mode == "zeros" and
+                c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and x.shape[-1] * x.shape[-2] >= 4096 and
+                (c.dilation[0] <= 2 or c.out_channels > 24) and os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
+            return "mfma"
         up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
         if x.shape[-1] * x.shape[-2] * up < 16384:
             return None
@@ -102,7 +109,56 @@ class Unit(nn.Module):
             self._fold_key = key
         return self._fold
 
+    def _folded_mfma(self):
+        """Weights split into bf16 terms in the operand layout of csrc/conv2d_mfma.hip + folded BN, cached per version."""
+        c, bn = self.conv, self.bn
+        ts = [c.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else
+                           ([c.bias] if c.bias is not None else []))
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_mfold_key", None) != key:
+            from . import _lib
+            L = _lib.lib()
+            with torch.no_grad():
+                co, ci, k = c.out_channels, c.in_channels, c.kernel_size[0]
+                if bn is not None:
+                    scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                    shift = bn.bias.float() - bn.running_mean.float() * scale
+                else:
+                    scale = torch.ones(co, device=c.weight.device)
+                    shift = c.bias.float() if c.bias is not None else torch.zeros(co, device=c.weight.device)
+                w = c.weight.detach().float().contiguous()
+                wp = torch.empty(L.decnet_conv2d_mfma_packed_bytes(ci, co, k), dtype=torch.uint8, device=w.device)
+                with torch.cuda.device(w.device):
+                    _lib.check(L.decnet_conv2d_mfma_pack_weight(w.data_ptr(), wp.data_ptr(), ci, co, k,
+                                                                torch.cuda.current_stream(w.device).cuda_stream),
+                               "decnet_conv2d_mfma_pack_weight")
+                self._mfold = (wp, scale.contiguous(), shift.contiguous())
+            self._mfold_key = key
+        return self._mfold
+
+    def _forward_mfma(self, x):
+        import ctypes
+        from . import _lib
+        from .ops import _stream
+        wp, scale, shift = self._folded_mfma()
+        xs = [t.contiguous() for t in (x if isinstance(x, (tuple, list)) else (x,))]
+        B, _, H, W = xs[0].shape
+        c = self.conv
+        assert sum(t.shape[1] for t in xs) == c.in_channels
+        y = torch.empty((B, c.out_channels, H, W), dtype=torch.float32, device=xs[0].device)
+        ptrs = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+        cins = (ctypes.c_int * len(xs))(*[int(t.shape[1]) for t in xs])
+        with torch.cuda.device(y.device):
+            rc = _lib.lib().decnet_conv2d_mfma_cat_bn_act(ptrs, cins, len(xs), wp.data_ptr(), scale.data_ptr(),
+                                                          shift.data_ptr(), y.data_ptr(), B, c.out_channels, H, W,
+                                                          c.kernel_size[0], c.dilation[0], 1 if self.relu else 0,
+                                                          _stream(y))
+        _lib.check(rc, "decnet_conv2d_mfma_cat_bn_act")
+        return y
+
     def _forward_hip(self, x, kind):
+        if kind == "mfma":
+            return self._forward_mfma(x)
         from . import _lib
         from .ops import _stream
         w, scale, shift = self._folded()

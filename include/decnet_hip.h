@@ -222,6 +222,16 @@ int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *sca
 int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, const float *w_packed,
                              const float *scale, const float *shift, float *y, int B, int Cout, int H,
                              int W, int k, int dilation, int relu, void *stream);
+/* The many-channel stride-1 Conv2dUnit layers (FeatureExtraction conv1-conv3_2 and the Deconv2dBlock convolutions
+ * submodule.py:245-343, 162-178; DynamicUpsampling.weight_learning :566-577; Refinement :690-717) on the bf16
+ * matrix cores at fp32 accuracy (each fp32 operand split into three bf16 terms, six partial products): k = 1 or 3,
+ * stride 1, padding dilation*(k/2), any Cin / Cout, input = channel concatenation of nseg (<= 6) tensors.
+ * Weights: torch [Cout,Cin,k,k] packed once into decnet_conv2d_mfma_packed_bytes(...) bytes (0: unsupported). */
+size_t decnet_conv2d_mfma_packed_bytes(int Cin, int Cout, int k);
+int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream);
+int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int nseg, const void *w_packed,
+                                  const float *scale, const float *shift, float *y, int B, int Cout, int H,
+                                  int W, int k, int dilation, int relu, void *stream);
 /* Refinement.get_warped_feats_by_homgrp (submodule.py:719-745): out[b,c,y,x] = bilinear(right[b,c];
  * (x - disp[b,y,x]) * W/(W-1) - 0.5, y * H/(H-1) - 0.5), zero padding.  right,out [B,C,H,W], disp [B,H,W]. */
 int decnet_warp_disparity(const float *right, const float *disp, float *out, int B, int C, int H, int W,

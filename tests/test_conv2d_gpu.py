@@ -39,10 +39,47 @@ def test_conv_unit_vs_torch_cpu(dev, cin, cout, k, dil, relu, bn):
     with torch.no_grad():
         ref = u(x)                                          # CPU: torch ops
         ud = u.to(dev)
-        assert ud._hip_kind(x.to(dev)) == "conv"
+        assert ud._hip_kind(x.to(dev)) == ("mfma" if (cin, cout, dil) == (49, 24, 2) else "conv")
         got = ud(x.to(dev)).cpu()
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+# the many-channel layers on the bf16 matrix cores (csrc/conv2d_mfma.hip): every (tile height, channel tile count)
+# variant, concatenated inputs, ragged sizes, dilation, 1x1; reference = torch CPU in float64
+@pytest.mark.parametrize("cins,cout,k,dil,relu,bn,shape,tm", [
+    ((81,), 81, 3, 1, True, True, (2, 61, 107), 6), ((81,), 81, 3, 1, True, True, (1, 60, 108), 5),
+    ((73,), 81, 3, 1, True, True, (1, 45, 100), 4), ((24, 24), 24, 3, 1, True, True, (2, 70, 131), 8),
+    ((24,), 24, 3, 1, True, True, (1, 33, 64), 2), ((72, 72, 1), 72, 3, 1, True, True, (2, 60, 108), 6),
+    ((72,), 36, 3, 1, True, True, (1, 64, 64), 8), ((36,), 36, 3, 1, False, True, (1, 40, 103), 5),
+    ((217,), 81, 3, 1, True, True, (1, 60, 108), 2), ((216,), 216, 3, 1, True, True, (1, 20, 36), 4),
+    ((24, 24, 1), 24, 3, 2, True, True, (1, 90, 162), 4), ((24,), 40, 3, 4, True, True, (1, 64, 70), 2),
+    ((24,), 24, 1, 1, True, True, (2, 64, 100), 8), ((432,), 216, 1, 1, True, True, (1, 20, 36), 5),
+    ((48,), 64, 3, 1, True, False, (1, 31, 47), 0), ((16,), 24, 3, 1, False, False, (1, 64, 64), 0)])
+def test_mfma_conv_unit_vs_torch_cpu(dev, monkeypatch, cins, cout, k, dil, relu, bn, shape, tm):
+    cin = sum(cins)
+    u = _unit(cin, cout, k, dil, relu, bn, seed=cin * 7 + cout)
+    g = torch.Generator().manual_seed(11)
+    B, H, W = shape
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    with torch.no_grad():
+        ref = u.double()(torch.cat(xs, 1).double())
+        ud = u.float().to(dev)
+        if tm:
+            monkeypatch.setenv("DECNET_CONV2D_MFMA_TM", str(tm))
+        xd = [t.to(dev) for t in xs]
+        got = ud._forward_mfma(xd if len(xd) > 1 else xd[0]).cpu()
+    assert got.shape == ref.shape
+    assert float((got.double() - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_mfma_conv_is_what_the_many_channel_units_run(dev):
+    u = _unit(72, 72, 3).to(dev)
+    x = torch.randn(2, 72, 60, 108, device=dev)
+    with torch.no_grad():
+        assert u._hip_kind(x) == "mfma"
+        assert _unit(144, 72, 3).to(dev)._hip_kind((x, x)) == "mfma"
+        assert u._hip_kind(x[:, :, :20, :36]) is None                             # small images stay on the library
 
 
 @pytest.mark.parametrize("cin,cout,relu,bn", [(24, 8, True, True), (9, 8, True, False), (24, 3, False, True)])
@@ -137,11 +174,14 @@ def test_aspp_tap_gemm_path(dev, c, rates, shape):
 
 
 def test_unit_falls_back_when_not_covered(dev):
-    u = _unit(24, 24, 3).to(dev)                            # 24 -> 24 channels, no dilation: MIOpen path
-    x = torch.randn(1, 24, 300, 300, device=dev)
+    u = _unit(216, 216, 3).to(dev)                          # many channels on a 20 x 36 image: library path
+    x = torch.randn(1, 216, 20, 36, device=dev)
     with torch.no_grad():
         assert u._hip_kind(x) is None
-        assert tuple(u(x).shape) == (1, 24, 300, 300)
+        got = u(x)
+        ref = u.cpu()(x.cpu())
+    assert tuple(got.shape) == (1, 216, 20, 36)
+    assert float((got.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("H,W,quant", [(131, 517, 0.5), (67, 64, 0.9), (5, 1000, 0.3)])

@@ -64,7 +64,7 @@ def main():
             rows.append((e0.elapsed_time(e1), name, shp, type(c).__name__, tuple(c.weight.shape), c.stride, c.dilation))
     tot = sum(r[0] for r in rows)
     print("Unit modules: %d calls, %.2f ms" % (len(rows), tot))
-    for r in sorted(rows, key=lambda r: -r[0])[:45]:
+    for r in sorted(rows, key=lambda r: -r[0])[:120]:
         print("%7.3f ms  %-42s in=%s %s w=%s s=%s d=%s" % r)
 
 
