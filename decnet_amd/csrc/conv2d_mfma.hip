@@ -28,7 +28,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef DECNET_C2M_ABLATE
-#define DECNET_C2M_ABLATE 0      // timing experiments only: 1 stage chunk 0 only, 2 never advance the weight pointer
+#define DECNET_C2M_ABLATE 0      // timing experiments only: 1 stage chunk 0 only, 2 never advance the weight pointer, 4 no A re-load, 8 no barriers
 #endif
 
 namespace {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
     __syncthreads();
     for (int ck = 0; ck < nchunk; ++ck) {
         const bool more = ck + 1 < nchunk;
-        if (more && !(DECNET_C2M_ABLATE & 1)) issue(ck + 1);   // in flight during this chunk's MFMAs
+        if (more && !(DECNET_C2M_ABLATE & 17)) issue(ck + 1);   // in flight during this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
         if (wave_active) {
             // every operand tile is re-loaded for the NEXT (tap, j) step right behind its last MFMA of this one: the B
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
                         for (int mt = 0; mt < TM; ++mt) {
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, a[mt]), __builtin_bit_cast(bf16x8, bq[nt]), acc[mt][nt], 0, 0, 0);
-                            if (nt == TN - 1) a[mt] = smem[nxt + mt * PW];
+                            if (nt == TN - 1 && !(DECNET_C2M_ABLATE & 4)) a[mt] = smem[nxt + mt * PW];
                         }
                         bq[nt] = wb[nt * 64];
                         __builtin_amdgcn_sched_barrier(0);
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
                 }
             }
         }
-        __syncthreads();                                           // the tile has been read by every wave
+        if (!(DECNET_C2M_ABLATE & 8)) __syncthreads();             // the tile has been read by every wave
         if (more) {
-            if (!(DECNET_C2M_ABLATE & 1)) commit();
-            __syncthreads();
+            if (!(DECNET_C2M_ABLATE & 33)) commit();
+            if (!(DECNET_C2M_ABLATE & 8)) __syncthreads();
         }
     }
 
@@ -256,9 +256,201 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
     }
 }
 
-// Rows per wave.  Workgroups run two per CU (512 slots); a launch costs (rounds of 512 workgroups) x (TM + a fixed
-// share for prologue, staging and epilogue), e.g. H = 180: TM = 5 gives 9 exact row tiles and 2.95 rounds at batch 8.
-inline int pick_tm(int B, int H, int W, int nchunkN, int tn, int pad) {
+// ---- producer / consumer variant (TN >= 4) ---------------------------------------------------------------------------
+// One 512-thread workgroup per CU: waves 0-3 issue only weight loads and MFMAs, waves 4-7 only stage (global loads of
+// the next chunk's halo tile, bf16 split, LDS stores into the other of two tiles); a SIMD holds one wave of each kind,
+// so the split's VALU work and the loads' latency run beside the matrix pipe instead of in front of it (in the
+// 4-wave kernel above the in-order vmcnt makes the first weight tile after issue() wait for the pixel loads too:
+// measured 0.371 ms on the 81 -> 81 layer at 180 x 324 against 0.28 ms with staging compiled out).  One barrier per
+// chunk.  The weight tiles of the three steps (j) of a tap live in a ring of 3 x TN operand registers and are
+// re-loaded three steps (~1400 cycles) ahead.
+template <int TM, int TN, int NU>
+__global__ __launch_bounds__(2 * THREADS, 1) void conv2d_mfma_pc(
+    Segs in, const i32x4 *__restrict__ wp, const float *__restrict__ scale, const float *__restrict__ shift,
+    float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x) {
+    constexpr int TH = 4 * TM;
+    extern __shared__ i32x4 smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pad = KT == 9 ? dil : 0;
+    const int PW = 16 + 2 * pad, PH = TH + 2 * pad, P = PW * PH;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int y0 = tyi * TH, x0 = txi * 16;
+    const int nt0 = blockIdx.y * TN;
+    const int b = blockIdx.z;
+    const size_t HW = (size_t)H * W;
+    const int tile_units = 6 * P;
+
+    if (wave >= 4) {
+        // ================= staging waves: 4-5 the channels 0-7 of a chunk, 6-7 the channels 8-15 =================
+        const int lt = tid - 4 * 64, sg = (wave - 4) >> 1;
+        int po[NU];                                            // pixel offset inside a channel plane, -1: zero
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int p = (lt & 127) + 128 * u;
+            const int py = p / PW, px = p - py * PW;
+            const int gy = y0 - pad + py, gx = x0 - pad + px;
+            po[u] = (p < P && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+        }
+        for (int ck = 0; ck <= nchunk; ++ck) {
+            if (ck < nchunk) {
+                float raw[NU][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 16 * ck + 8 * sg + e;
+                    const float *cp = nullptr;
+                    int base = 0;
+#pragma unroll
+                    for (int s = 0; s < MAXSEG; ++s) {
+                        if (s < in.n) {
+                            if (c >= base && c < base + in.c[s]) cp = in.p[s] + ((size_t)b * in.c[s] + (c - base)) * HW;
+                            base += in.c[s];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        float v = 0.f;
+                        if (cp != nullptr && po[u] >= 0) v = cp[po[u]];
+                        raw[u][e] = v;
+                    }
+                }
+                i32x4 *tile = smem + (ck & 1) * tile_units;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int p = (lt & 127) + 128 * u;
+                    if (p >= P) break;
+                    int h[8], m[8], l[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) split3(raw[u][e], h[e], m[e], l[e]);
+                    i32x4 th, tm, tl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        th[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302);
+                        tm[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302);
+                        tl[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302);
+                    }
+                    tile[(0 * 2 + sg) * P + p] = th;
+                    tile[(1 * 2 + sg) * P + p] = tm;
+                    tile[(2 * 2 + sg) * P + p] = tl;
+                }
+            }
+            // barrier ck: tile ck is complete, and the MFMA waves have finished with tile ck - 1 (= tile ck + 1's place)
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================= MFMA waves =================
+    const int r = lane & 15, q = lane >> 4;
+    int offA[3];
+    offA[0] = ((q >> 1) * 2 + 0) * P + r;
+    offA[1] = ((q >> 1) * 2 + 1) * P + r;
+    offA[2] = (((q & 1) ? 2 : 0) * 2 + (q >> 1)) * P + r;
+    const int rowbase = wave * TM;
+    const bool wave_active = y0 + rowbase < H;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const i32x4 *wb = wp + (size_t)nt0 * 64 + lane;          // advances NT * 64 per (chunk, tap, j)
+    const int wstep = NT * 64;
+    i32x4 bq[3][TN];                                           // weight tiles of the steps j = 0, 1, 2 of a tap
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) bq[j][nt] = wb[j * wstep + nt * 64];
+
+    __syncthreads();                                           // barrier 0: tile 0
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const i32x4 *cur = smem + (ck & 1) * tile_units;
+        if (wave_active) {
+            i32x4 a[TM];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) a[mt] = cur[offA[0] + rowbase * PW + mt * PW];
+            for (int tap = 0; tap < KT; ++tap) {
+                const int tn_ = tap + 1 < KT ? tap + 1 : 0;
+                const int tyn = KT == 9 ? tn_ / 3 : 0, txn = KT == 9 ? tn_ - 3 * tyn : 0;
+                const int ty = KT == 9 ? tap / 3 : 0, tx = KT == 9 ? tap - 3 * ty : 0;
+                const int tapoff = (rowbase + ty * dil) * PW + tx * dil;
+                const int tapoff_n = (rowbase + tyn * dil) * PW + txn * dil;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int nxt = j < 2 ? offA[j + 1] + tapoff : offA[0] + tapoff_n;
+                    // columns 0 .. TN-G-1 one at a time (weight tile re-loaded behind its TM MFMAs), the last G columns
+                    // row by row so that a pixel tile's re-load has (TM - 1) G MFMAs to land before the next step
+                    constexpr int G = TN < 3 ? TN : 3;
+#pragma unroll
+                    for (int nt = 0; nt < TN - G; ++nt) {
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a[mt]), __builtin_bit_cast(bf16x8, bq[j][nt]), acc[mt][nt], 0,
+                                0, 0);
+                        bq[j][nt] = wb[3 * wstep + nt * 64];   // same j of the next tap (3 blocks of padding at the end)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+                        for (int nt = TN - G; nt < TN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a[mt]), __builtin_bit_cast(bf16x8, bq[j][nt]), acc[mt][nt], 0,
+                                0, 0);
+                        a[mt] = cur[nxt + mt * PW];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int nt = TN - G; nt < TN; ++nt) bq[j][nt] = wb[3 * wstep + nt * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    wb += wstep;
+                }
+            }
+        }
+        __syncthreads();                                       // barrier ck + 1
+    }
+
+    // ---- epilogue: lane holds output channel n = tile * 16 + r, pixels x0 + 4 q .. + 3 of each row ----
+    if (!wave_active) return;
+    const int xq = x0 + 4 * q;
+    const bool vec = (W & 3) == 0 && xq + 3 < W;
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int n = (nt0 + nt) * 16 + r;
+        if (n >= Cout) continue;
+        const float sc = scale[n], sh = shift[n];
+        float *yp = y + ((size_t)b * Cout + n) * HW;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int row = y0 + rowbase + mt;
+            if (row >= H) break;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = fmaf(v[i], sc, sh);
+                if (relu) v[i] = fmaxf(v[i], 0.f);
+            }
+            float *dst = yp + (size_t)row * W + xq;
+            if (vec) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xq + i < W) dst[i] = v[i];
+            }
+        }
+    }
+}
+
+// Rows per wave.  A launch costs (rounds of resident workgroups) x (TM + a fixed share for prologue, staging and
+// epilogue); e.g. H = 180: TM = 5 gives 9 exact row tiles.  pc: the producer / consumer kernel (one workgroup per CU).
+constexpr bool fits(int tm, int tn, bool pc) {                       // accumulators + operands within 256 registers
+    if (pc) return tm * tn * 4 + tm * 4 + tn * 12 + 30 <= 256;
+    return tm * tn <= 36 || (tm == 8 && tn <= 4);
+}
+inline int pick_tm(int B, int H, int W, int nchunkN, int tn, int pad, bool pc) {
     const char *env = getenv("DECNET_CONV2D_MFMA_TM");                     // tests / experiments: pin the tile height
     const int forced = env ? atoi(env) : 0;
     static const int cand[5] = {8, 6, 5, 4, 2};
@@ -266,54 +458,67 @@ inline int pick_tm(int B, int H, int W, int nchunkN, int tn, int pad) {
     double best_cost = 1e30;
     for (int i = 0; i < 5; ++i) {
         const int tm = cand[i];
-        if (tm * tn > 36 && !(tm == 8 && tn <= 4)) continue;             // accumulators + operands within 256 registers
+        if (!fits(tm, tn, pc)) continue;
         if (pad > 1 && tm > 4) continue;
         if (forced == tm) return tm;
         const double wgs = (double)ceil_div(W, 16) * ceil_div(H, 4 * tm) * B * nchunkN;
-        const double cost = ceil(wgs / 512.0) * (tm + 0.7);
+        const double cost = ceil(wgs / (pc ? 256.0 : 512.0)) * (tm + (pc ? 0.4 : 0.7));
         if (cost < best_cost) { best_cost = cost; best = tm; }
     }
     return best;
 }
 
-template <int TM, int TN, int NU>
+template <int TM, int TN, int NU, bool PC>
 int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shift, float *y, int B, int Cout, int H,
            int W, int KT, int dil, int relu, int nchunk, int NT, hipStream_t stream) {
     const int pad = KT == 9 ? dil : 0;
-    const size_t lds = (size_t)(16 + 2 * pad) * (4 * TM + 2 * pad) * 6 * 16;
-    static bool attr = false;                                  // idempotent; a race sets the same value twice
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)conv2d_mfma<TM, TN, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  DECNET_LDS_BYTES);
-        attr = true;
-    }
+    const size_t lds = (size_t)(16 + 2 * pad) * (4 * TM + 2 * pad) * 6 * 16 * (PC ? 2 : 1);
+    if (lds > DECNET_LDS_BYTES) return DECNET_ERR_UNSUPPORTED;
     const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 4 * TM);
     const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(NT / TN), (unsigned)B);
-    hipLaunchKernelGGL((conv2d_mfma<TM, TN, NU>), grid, dim3(THREADS), lds, stream, in, wp, scale, shift, y, Cout, H, W,
-                       KT, dil, relu, nchunk, NT, tiles_x);
+    static bool attr = false;                                  // idempotent; a race sets the same value twice
+    if constexpr (PC) {
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)conv2d_mfma_pc<TM, TN, NU>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, DECNET_LDS_BYTES);
+            attr = true;
+        }
+        hipLaunchKernelGGL((conv2d_mfma_pc<TM, TN, NU>), grid, dim3(2 * THREADS), lds, stream, in, wp, scale, shift, y,
+                           Cout, H, W, KT, dil, relu, nchunk, NT, tiles_x);
+    } else {
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)conv2d_mfma<TM, TN, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DECNET_LDS_BYTES);
+            attr = true;
+        }
+        hipLaunchKernelGGL((conv2d_mfma<TM, TN, NU>), grid, dim3(THREADS), lds, stream, in, wp, scale, shift, y, Cout, H,
+                           W, KT, dil, relu, nchunk, NT, tiles_x);
+    }
     return decnet_launch_status();
 }
 
 // pixels of the halo tile of a TM variant
 inline int tile_pixels(int tm, int pad) { return (16 + 2 * pad) * (4 * tm + 2 * pad); }
 
-template <int TN>
+template <int TN, bool PC>
 int launch_tm(int tm, const Segs &in, const i32x4 *wp, const float *scale, const float *shift, float *y, int B,
               int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, hipStream_t stream) {
     const int pad = KT == 9 ? dil : 0;
 #define ARGS in, wp, scale, shift, y, B, Cout, H, W, KT, dil, relu, nchunk, NT, stream
     if (pad <= 1) {
-        if constexpr (TN <= 4) {
-            if (tm == 8) return launch<8, TN, 5>(ARGS);
+        if constexpr (fits(8, TN, PC)) {
+            if (tm == 8) return launch<8, TN, 5, PC>(ARGS);
         }
-        if (tm == 6) return launch<6, TN, 4>(ARGS);
-        if (tm == 5) return launch<5, TN, 4>(ARGS);
-        if (tm == 4) return launch<4, TN, 3>(ARGS);
-        return launch<2, TN, 2>(ARGS);
+        if constexpr (fits(6, TN, PC)) {
+            if (tm == 6) return launch<6, TN, 4, PC>(ARGS);
+        }
+        if (tm == 5) return launch<5, TN, 4, PC>(ARGS);
+        if (tm == 4) return launch<4, TN, 3, PC>(ARGS);
+        return launch<2, TN, 2, PC>(ARGS);
     }
     // dilated taps: bigger halo, 5 staging units per thread (640 pixels)
-    if (tm >= 4 && tile_pixels(4, pad) <= 640) return launch<4, TN, 5>(ARGS);
-    if (tile_pixels(2, pad) <= 640) return launch<2, TN, 5>(ARGS);
+    if (tm >= 4 && tile_pixels(4, pad) <= 640) return launch<4, TN, 5, PC>(ARGS);
+    if (tile_pixels(2, pad) <= 640) return launch<2, TN, 5, PC>(ARGS);
 #undef ARGS
     return DECNET_ERR_UNSUPPORTED;
 }
@@ -324,7 +529,7 @@ extern "C" {
 
 size_t decnet_conv2d_mfma_packed_bytes(int Cin, int Cout, int k) {
     if (Cin < 1 || Cout < 1 || (k != 1 && k != 3)) return 0;
-    const size_t blocks = (size_t)ceil_div(Cin, 16) * (k * k) * 3 + 1;       // + 1: the prefetch runs one block ahead
+    const size_t blocks = (size_t)ceil_div(Cin, 16) * (k * k) * 3 + 3;       // + 3: the prefetch runs three blocks ahead
     return blocks * padded_nt(Cout) * 64 * 16;
 }
 
@@ -361,12 +566,24 @@ int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int n
     if (B > 65535 || Cin > 65536 || (double)H * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;
     const int TN = pick_tn(Cout), NT = padded_nt(Cout), nchunk = ceil_div((int)Cin, 16);
     if (NT / TN > 65535 || (double)ceil_div(W, 16) * ceil_div(H, 8) >= 2.0e9) return DECNET_ERR_UNSUPPORTED;
-    const int tm = pick_tm(B, H, W, NT / TN, TN, k == 3 ? dilation : 0);
+    // the 4-wave kernel (two workgroups per CU) when its grid fills the chip at least once, else the 8-wave
+    // producer / consumer kernel (TN >= 4: measured 217 -> 81 at 60 x 108, 448 workgroups: 0.156 vs 0.104 ms;
+    // 81 -> 81 at 180 x 324, 1512 workgroups: 0.371 vs 0.390 ms)
+    const int pad = k == 3 ? dilation : 0;
+    int tm = pick_tm(B, H, W, NT / TN, TN, pad, false);
+    const char *env = getenv("DECNET_CONV2D_MFMA_PC");                      // tests / experiments: 0 / 1 pins the kernel
+    bool pc = TN >= 4 && (double)ceil_div(W, 16) * ceil_div(H, 4 * tm) * B * (NT / TN) <= 512.0;
+    if (env && TN >= 4) pc = atoi(env) != 0;
+    if (pc) tm = pick_tm(B, H, W, NT / TN, TN, pad, true);
     const i32x4 *wp = (const i32x4 *)w_packed;
     hipStream_t st = (hipStream_t)stream;
-#define GO(T) case T: return launch_tm<T>(tm, in, wp, scale, shift, y, B, Cout, H, W, k * k, dilation, relu, nchunk, NT, st)
+#define GO(T, P) return launch_tm<T, P>(tm, in, wp, scale, shift, y, B, Cout, H, W, k * k, dilation, relu, nchunk, NT, st)
     switch (TN) {
-        GO(2); GO(3); GO(4); GO(5); GO(6);
+        case 2: GO(2, false);
+        case 3: GO(3, false);
+        case 4: if (pc) GO(4, true); else GO(4, false);
+        case 5: if (pc) GO(5, true); else GO(5, false);
+        case 6: if (pc) GO(6, true); else GO(6, false);
     }
 #undef GO
     return DECNET_ERR_UNSUPPORTED;

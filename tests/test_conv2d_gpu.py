@@ -68,9 +68,13 @@ def test_mfma_conv_unit_vs_torch_cpu(dev, monkeypatch, cins, cout, k, dil, relu,
         if tm:
             monkeypatch.setenv("DECNET_CONV2D_MFMA_TM", str(tm))
         xd = [t.to(dev) for t in xs]
-        got = ud._forward_mfma(xd if len(xd) > 1 else xd[0]).cpu()
-    assert got.shape == ref.shape
-    assert float((got.double() - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max()))
+        # >= 49 output channels: both the 4-wave and the 8-wave producer / consumer kernel
+        for pc in (("0", "1") if cout > 48 else ("",)):
+            if pc:
+                monkeypatch.setenv("DECNET_CONV2D_MFMA_PC", pc)
+            got = ud._forward_mfma(xd if len(xd) > 1 else xd[0]).cpu()
+            assert got.shape == ref.shape
+            assert float((got.double() - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max())), pc
 
 
 def test_mfma_conv_is_what_the_many_channel_units_run(dev):
