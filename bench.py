@@ -281,7 +281,7 @@ def e2e_bench(B, dev, iters=5):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
         res = {"value": B / dt, "unit": "pairs/s", "ms_per_batch": 1e3 * dt, "batch": B,
-               "note": "full graph: fused HIP small-channel 2-D convs + MIOpen for the rest + the MI355X "
+               "note": "full graph: fused HIP small-channel 2-D convs + bf16x3 matrix-core many-channel convs + MIOpen for the stride-3 / small-image rest + the MI355X "
                        "hot-path kernels, eager launches"}
         # the same forward captured once into a HIP graph (static shapes) and replayed: no launch gaps
         try:
