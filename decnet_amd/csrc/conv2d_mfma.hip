@@ -92,7 +92,8 @@ __global__ void conv2d_mfma_pack(const float *__restrict__ w, i32x4 *__restrict_
 template <int TM, int TN, int NU>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
     Segs in, const i32x4 *__restrict__ wp, const float *__restrict__ scale, const float *__restrict__ shift,
-    float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x) {
+    float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x,
+    int tail8) {
     constexpr int TH = 4 * TM;
     extern __shared__ i32x4 smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
     __syncthreads();
     for (int ck = 0; ck < nchunk; ++ck) {
         const bool more = ck + 1 < nchunk;
+        const bool skip1 = !more && tail8;
         if (more && !(DECNET_C2M_ABLATE & 17)) issue(ck + 1);   // in flight during this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
         if (wave_active) {
@@ -201,8 +203,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
                 const int tapoff_n = (rowbase + tyn * dil) * PW + txn * dil;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    if (!(DECNET_C2M_ABLATE & 2)) wb += wstep;     // the packed buffer ends with one block of padding
-                    const int nxt = j < 2 ? offA[j + 1] + tapoff : offA[0] + tapoff_n;
+                    // last chunk with <= 8 real channels: its j = 1 step (channels 8-15) is all padding
+                    if (j == 1 && skip1) continue;
+                    if (!(DECNET_C2M_ABLATE & 2)) wb += (j == 0 && skip1) ? 2 * wstep : wstep;   // -> the next step's tiles
+                    const int nxt = j == 0 ? offA[skip1 ? 2 : 1] + tapoff : j == 1 ? offA[2] + tapoff : offA[0] + tapoff_n;
 #pragma unroll
                     for (int nt = 0; nt < TN; ++nt) {
 #pragma unroll
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
 template <int TM, int TN, int NU>
 __global__ __launch_bounds__(2 * THREADS, 1) void conv2d_mfma_pc(
     Segs in, const i32x4 *__restrict__ wp, const float *__restrict__ scale, const float *__restrict__ shift,
-    float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x) {
+    float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x,
+    int tail8) {
     constexpr int TH = 4 * TM;
     extern __shared__ i32x4 smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(2 * THREADS, 1) void conv2d_mfma_pc(
     __syncthreads();                                           // barrier 0: tile 0
     for (int ck = 0; ck < nchunk; ++ck) {
         const i32x4 *cur = smem + (ck & 1) * tile_units;
+        const bool skip1 = ck + 1 == nchunk && tail8;
         if (wave_active) {
             i32x4 a[TM];
 #pragma unroll
@@ -378,7 +384,11 @@ __global__ __launch_bounds__(2 * THREADS, 1) void conv2d_mfma_pc(
                 const int tapoff_n = (rowbase + tyn * dil) * PW + txn * dil;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const int nxt = j < 2 ? offA[j + 1] + tapoff : offA[0] + tapoff_n;
+                    if (j == 1 && skip1) {                             // all-padding step of the last chunk
+                        wb += wstep;
+                        continue;
+                    }
+                    const int nxt = j == 0 ? offA[skip1 ? 2 : 1] + tapoff : j == 1 ? offA[2] + tapoff : offA[0] + tapoff_n;
                     // columns 0 .. TN-G-1 one at a time (weight tile re-loaded behind its TM MFMAs), the last G columns
                     // row by row so that a pixel tile's re-load has (TM - 1) G MFMAs to land before the next step
                     constexpr int G = TN < 3 ? TN : 3;
@@ -474,6 +484,9 @@ int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shi
     const int pad = KT == 9 ? dil : 0;
     const size_t lds = (size_t)(16 + 2 * pad) * (4 * TM + 2 * pad) * 6 * 16 * (PC ? 2 : 1);
     if (lds > DECNET_LDS_BYTES) return DECNET_ERR_UNSUPPORTED;
+    int cin = 0;
+    for (int i = 0; i < in.n; ++i) cin += in.c[i];
+    const int tail8 = cin - 16 * (nchunk - 1) <= 8;              // the last chunk's channels 8-15 are padding
     const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 4 * TM);
     const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(NT / TN), (unsigned)B);
     static bool attr = false;                                  // idempotent; a race sets the same value twice
@@ -484,7 +497,7 @@ int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shi
             attr = true;
         }
         hipLaunchKernelGGL((conv2d_mfma_pc<TM, TN, NU>), grid, dim3(2 * THREADS), lds, stream, in, wp, scale, shift, y,
-                           Cout, H, W, KT, dil, relu, nchunk, NT, tiles_x);
+                           Cout, H, W, KT, dil, relu, nchunk, NT, tiles_x, tail8);
     } else {
         if (!attr) {
             (void)hipFuncSetAttribute((const void *)conv2d_mfma<TM, TN, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -492,7 +505,7 @@ int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shi
             attr = true;
         }
         hipLaunchKernelGGL((conv2d_mfma<TM, TN, NU>), grid, dim3(THREADS), lds, stream, in, wp, scale, shift, y, Cout, H,
-                           W, KT, dil, relu, nchunk, NT, tiles_x);
+                           W, KT, dil, relu, nchunk, NT, tiles_x, tail8);
     }
     return decnet_launch_status();
 }

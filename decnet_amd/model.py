@@ -58,7 +58,7 @@ class Unit(nn.Module):
         if (isinstance(c, nn.Conv2d) and c.out_channels >= 24 and c.in_channels >= 16 and c.kernel_size in ((1, 1), (3, 3)) and
                 c.stride == (1, 1) and c.dilation[0] == c.dilation[1] and c.groups == 1 and c.padding_mode == "zeros" and
                 c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and x.shape[-1] * x.shape[-2] >= 4096 and
-                (c.dilation[0] <= 2 or c.out_channels > 24) and os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
+                c.dilation[0] <= 4 and os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma"
         up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
         if x.shape[-1] * x.shape[-2] * up < 16384:
