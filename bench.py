@@ -258,6 +258,17 @@ def cpu_baseline(seed=17, budget_s=12.0, max_pairs=16):
                       % (n, t_s0 / n, t_sp / n)}
 
 
+def pack_mask_bits(mask):
+    """float 0/1 [B,H,W] (device) -> int64 [B,H,ceil(W/64)], bit i of word w = pixel 64 w + i."""
+    import torch
+    B, H, W = mask.shape
+    wpr = (W + 63) // 64
+    z = torch.zeros(B, H, wpr * 64, dtype=torch.int64, device=mask.device)
+    z[:, :, :W] = (mask != 0).long()
+    sh = torch.arange(64, device=mask.device, dtype=torch.int64)
+    return (z.view(B, H, wpr, 64) << sh).sum(-1).contiguous()
+
+
 def e2e_bench(B, dev, iters=5):
     """Whole network forward (random-init weights, demo.sh hyper-parameters, thold 0.5 so that the
     untrained mask generator produces mixed masks) on B synthetic 960x540 pairs padded to 972x540."""
@@ -654,12 +665,24 @@ def main():
                     by_density.append({"mask_density": dens, "ms": t, "achieved": used / t / 1e6,
                                        "frac": used / t / 1e6 / HBM_PEAK_GBS, "traffic": tr,
                                        "algorithmic_bytes": s3_bytes, "bytes_counted_for_achieved": used})
+                    # the same pass with the masks as the bit-packed copies decnet_detail_mask writes
+                    # (decnet_spamatvar_forward_bits: identical outputs, 8 of the 88 bytes per pixel not read).
+                    # frac_algorithmic: SURVEY 8d's byte count of the pass (float mask planes, what the reference
+                    # interface moves) / time, capped at the peak; frac_moved: PMC-counted bytes / time.
+                    rb, tb = pack_mask_bits(m2[3][0]), pack_mask_bits(m2[3][1])
+                    tb_ms = time_kernel(lambda: hp.decnet.spamatvar_forward_bits(Lf, Rf, rb, tb, D3, out=hp.outs[2]), 10)
+                    trb = traffic.get("spamat_fused_bits_stage3_density_%.2f" % dens, {}).get("total_bytes")
+                    trb = trb * (B / 8.0) if trb else None
+                    by_density[-1]["bit_masks"] = {
+                        "ms": tb_ms, "traffic": trb,
+                        "frac_algorithmic": min(1.0, s3_bytes / tb_ms / 1e6 / HBM_PEAK_GBS),
+                        "frac_moved": (trb / tb_ms / 1e6 / HBM_PEAK_GBS) if trb else None}
                     if dens == 0.1:
                         sparse = {"bound": "hbm", "achieved": used / t / 1e6, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": used / t / 1e6 / HBM_PEAK_GBS, "traffic": tr,
                                   "kernel": "spamat sparse-row kernel (+ marker launch), fused fwd, stage 3",
                                   "mask_density": 0.1, "ms": t, "algorithmic_bytes": s3_bytes,
-                                  "bytes_counted_for_achieved": used}
+                                  "bytes_counted_for_achieved": used, "bit_masks": by_density[-1]["bit_masks"]}
             # the dense pass against the bound that applies to it: instruction issue (VALU + fp32 MFMA)
             valu = None
             if args.mask_density >= 1.0:

@@ -12,10 +12,10 @@ from .modules.SparseMatching.modules.SpaMat import SpaMat  # noqa: F401
 from .modules.SparseMatching.functions.SpaMat import SpaMatFunction  # noqa: F401
 from .modules.SparseVar.modules.SpaVar import SpaVar  # noqa: F401
 from .modules.SparseVar.functions.SpaVar import SpaVarFunction  # noqa: F401
-from .ops import spamatvar_forward  # noqa: F401
+from .ops import spamatvar_forward, spamatvar_forward_bits  # noqa: F401
 from .stage0 import (CostRegNetNoDown, GetCostVolume, Stage0, disparity_regression,  # noqa: F401
                      get_disp_samples)
 
-__all__ = ["SpaMat", "SpaVar", "SpaMatFunction", "SpaVarFunction", "spamatvar_forward",
+__all__ = ["SpaMat", "SpaVar", "SpaMatFunction", "SpaVarFunction", "spamatvar_forward", "spamatvar_forward_bits",
            "GetCostVolume", "CostRegNetNoDown", "disparity_regression", "get_disp_samples",
            "Stage0", "DecnetHipError", "version"]

@@ -21,6 +21,7 @@ SIGNATURES = {
     "decnet_spavar_forward": [_P] * 8 + [_I] * 5 + [_P],
     "decnet_spavar_backward": [_P] * 12 + [_I] * 5 + [_P],
     "decnet_spamatvar_forward": [_P] * 8 + [_I] * 5 + [_P],
+    "decnet_spamatvar_forward_bits": [_P] * 8 + [_I] * 5 + [_P],
     "decnet_costvol_forward": [_P] * 3 + [_I] * 5 + [_P],
     "decnet_conv3d_packed_cout": [_I],
     "decnet_conv3d_pack_weight": [_P, _P, _I, _I, _P],

@@ -17,7 +17,7 @@ int decnet_check_spamat_args(const void *const *ptrs, int n, int B, int C, int H
 int decnet_mfma_forward(int mode, const float *ref, const float *tar, const float *rmask,
                         const float *tmask, const float *disparity, float *out, float *var_out,
                         float *sum_sim, float *max_cost, int B, int C, int H, int W, int max_disp,
-                        int allow_compact, hipStream_t stream);
+                        int allow_compact, int mbits, hipStream_t stream);
 
 // kernels in spamat_bwd_mfma.hip
 int decnet_mfma_backward(int var, const float *ref, const float *tar, const float *rmask,
@@ -67,7 +67,7 @@ static int forward_dispatch(int mode, const float *ref, const float *tar, const 
     const int pinned = spamat_pinned();
     if (pinned != 1) {
         int rc = decnet_mfma_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
-                                     max_cost, B, C, H, W, max_disp, pinned != 3, stream);
+                                     max_cost, B, C, H, W, max_disp, pinned != 3, 0, stream);
         if (rc != DECNET_ERR_UNSUPPORTED || pinned >= 2) return rc;
     }
     return decnet_rowtile_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
@@ -111,6 +111,20 @@ int decnet_spamatvar_forward(const float *ref, const float *tar, const float *re
     return forward_dispatch(2, ref, tar, ref_mask, tar_mask, nullptr, output, variance,
                                   sum_similarities, max_cost, B, C, H, W, max_disp,
                                   (hipStream_t)stream);
+}
+
+int decnet_spamatvar_forward_bits(const float *ref, const float *tar, const unsigned long long *ref_bits,
+                                  const unsigned long long *tar_bits, float *output, float *variance,
+                                  float *sum_similarities, float *max_cost, int B, int C, int H, int W,
+                                  int max_disp, void *stream) {
+    const void *p[] = {ref, tar, ref_bits, tar_bits, output, variance, sum_similarities, max_cost};
+    int rc = decnet_check_spamat_args(p, 8, B, C, H, W, max_disp);
+    if (rc) return rc;
+    // the matrix-core kernels only (the row-tile fallback reads float planes): band of <= 18 tiles, i.e. max_disp <= 272
+    return decnet_mfma_forward(2, ref, tar, reinterpret_cast<const float *>(ref_bits),
+                               reinterpret_cast<const float *>(tar_bits), nullptr, output, variance,
+                               sum_similarities, max_cost, B, C, H, W, max_disp, spamat_pinned() != 3, 1,
+                               (hipStream_t)stream);
 }
 
 int decnet_spamat_backward(const float *ref, const float *tar, const float *ref_mask,

@@ -68,6 +68,13 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, in
     return v;
 }
 
+// 4 activity flags of the pixels x .. x + 3 (x a multiple of 4) out of a row of bit-packed masks (bit i of word w =
+// pixel 64 w + i, zero past W: decnet_detail_mask's layout); positions outside the row read as inactive.
+__device__ __forceinline__ int mask4_bits(const unsigned long long *__restrict__ rowbits, int x, int W) {
+    if (x < 0 || x >= W) return 0;
+    return (int)((rowbits[x >> 6] >> (x & 63)) & 15ull);
+}
+
 // fp32 -> three bf16 terms x = hi + mid + lo (truncations with exact residuals: 24 mantissa bits
 // together), 8 values -> three packed 8 x bf16 MFMA operands.
 __device__ __forceinline__ void split3x8(const float (&x)[8], i32x4 &hi, i32x4 &mid, i32x4 &lo) {
@@ -464,7 +471,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int XT, int allow_compact, int marker, int seg, int row, int compact_pct) {
+    int H, int W, int D, int XT, int allow_compact, int marker, int seg, int row, int compact_pct, int mbits) {
     // marker: this launch follows spamat_fwd_sparse, which left -1 in sum_sim[row start] of exactly
     // the rows it did not take, at the first pixel of every segment (a real sum_similarities is never
     // negative)
@@ -494,6 +501,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const float *trow = tmask + (size_t)row * W;
     const float *mrow = rmask + (size_t)row * W;
     const size_t rowpix = (size_t)row * W;
+    // mbits: the mask arguments are bit-packed rows of ceil(W / 64) 64-bit words instead of float planes
+    const unsigned long long *tbits = reinterpret_cast<const unsigned long long *>(tmask) + (size_t)row * ((W + 63) >> 6);
+    const unsigned long long *lbits = reinterpret_cast<const unsigned long long *>(rmask) + (size_t)row * ((W + 63) >> 6);
 
     // ---------------- phase 1: masks -> LDS, flags kept in registers, block-wide counts ----------
     const int p4 = tid * 4;                          // this thread's 4 positions (RP, SW <= 2048)
@@ -502,8 +512,12 @@ __device__ __forceinline__ void spamat_fwd_segment(
         const bool alm = (((uintptr_t)trow) & 15) == 0 && (((uintptr_t)mrow) & 15) == 0;
         if (p4 < nRw) {
             const int x = xs - HALO + p4;
-            float4 tv = load4(trow, x, W, alm);
-            fr = (tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3);
+            if (mbits) {
+                fr = mask4_bits(tbits, x, W);
+            } else {
+                float4 tv = load4(trow, x, W, alm);
+                fr = (tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3);
+            }
             float4 bv4;
             bv4.x = (fr & 1) ? 0.f : NEG_BIG;
             bv4.y = (fr & 2) ? 0.f : NEG_BIG;
@@ -512,8 +526,14 @@ __device__ __forceinline__ void spamat_fwd_segment(
             *reinterpret_cast<float4 *>(BX + p4) = bv4;
         }
         if (p4 < SW) {
-            float4 mv = load4(mrow, xs + p4, W, alm);
-            fl = (mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3);
+            float4 mv;
+            if (mbits) {
+                fl = mask4_bits(lbits, xs + p4, W);
+                mv = make_float4((fl & 1) ? 1.f : 0.f, (fl & 2) ? 1.f : 0.f, (fl & 4) ? 1.f : 0.f, (fl & 8) ? 1.f : 0.f);
+            } else {
+                mv = load4(mrow, xs + p4, W, alm);
+                fl = (mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3);
+            }
             *reinterpret_cast<float4 *>(LM + p4) = mv;
         }
     }
@@ -822,10 +842,10 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker, int compact_pct) {
+    int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker, int compact_pct, int mbits) {
     spamat_fwd_segment<NT, MODE, KQ, D16>(ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W,
                                           D, XT, allow_compact, marker, blockIdx.x % segs_per_row,
-                                          blockIdx.x / segs_per_row, compact_pct);
+                                          blockIdx.x / segs_per_row, compact_pct, mbits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -851,7 +871,7 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int seg_w, int dense_pct) {
+    int H, int W, int D, int seg_w, int dense_pct, int mbits) {
     // at most 8 cost tiles per span (32 accumulator registers: six workgroups per CU); a row whose
     // disparity windows hold more than 8*16-15 active right pixels even for 16-pixel spans goes to
     // spamat_fwd_mfma like the dense ones
@@ -883,9 +903,15 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
 #pragma unroll
         for (int u = 0; u < PPT; u += 4) {
             if (p4 + u < W) {
-                const float4 tv = load4(trow, p4 + u, W, alm), mv = load4(mrow, p4 + u, W, alm);
-                fr |= ((tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3)) << u;
-                fl |= ((mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3)) << u;
+                if (mbits) {
+                    const int wpr = (W + 63) >> 6;
+                    fr |= mask4_bits(reinterpret_cast<const unsigned long long *>(tmask) + (size_t)row * wpr, p4 + u, W) << u;
+                    fl |= mask4_bits(reinterpret_cast<const unsigned long long *>(rmask) + (size_t)row * wpr, p4 + u, W) << u;
+                } else {
+                    const float4 tv = load4(trow, p4 + u, W, alm), mv = load4(mrow, p4 + u, W, alm);
+                    fr |= ((tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3)) << u;
+                    fl |= ((mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3)) << u;
+                }
             }
         }
     }
@@ -1042,7 +1068,7 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
 template <int NT, int KQ>
 int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
-              int B, int C, int H, int W, int D, int allow_compact, hipStream_t stream) {
+              int B, int C, int H, int W, int D, int allow_compact, int mbits, hipStream_t stream) {
     const int xt_row = ceil_div(W, 16);
     // dense rows on the bf16 matrix cores (dense16_body) for the shipped channel counts (C = 8, 24) unless
     // DECNET_SPAMAT_DENSE=fp32 or the compaction paths are pinned off; it needs more LDS per staged position
@@ -1093,7 +1119,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_sparse<NT, M, (KQ ? KQ : 1), P>), dim3((unsigned)(B * H)),  \
                            dim3(SP_THREADS), slds, stream, ref, tar, rmask, tmask, disparity, out, \
-                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16, compact_pct);          \
+                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16, compact_pct, mbits);   \
     } while (0)
 #define LAUNCHSP(M)                                                                                \
     do {                                                                                           \
@@ -1117,7 +1143,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ, DD>), grid, block, lds, stream, ref, tar, rmask, \
                            tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT, \
-                           allow_compact, marker, compact_pct);                                    \
+                           allow_compact, marker, compact_pct, mbits);                             \
     } while (0)
 #define LAUNCH(M)                                                                                  \
     do {                                                                                           \
@@ -1139,10 +1165,10 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
 template <int NT>
 int launch_kq(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
-              int B, int C, int H, int W, int D, int allow_compact, hipStream_t stream) {
+              int B, int C, int H, int W, int D, int allow_compact, int mbits, hipStream_t stream) {
 #define GO(K)                                                                                      \
     return launch_nt<NT, K>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,        \
-                            max_cost, B, C, H, W, D, allow_compact, stream)
+                            max_cost, B, C, H, W, D, allow_compact, mbits, stream)
     if (C <= 8 && C > 4) GO(2);        // stage 3 of the shipped network (C = 8)
 #ifdef DECNET_DEV_STAGE3               // tools/dev_spamat.sh: the stage-3 instantiation only (seconds to compile)
     return DECNET_ERR_UNSUPPORTED;
@@ -1160,15 +1186,16 @@ int launch_kq(int mode, const float *ref, const float *tar, const float *rmask, 
 // mode: 0 SpaMat, 1 SpaVar, 2 fused.  Returns DECNET_ERR_UNSUPPORTED when the band needs more
 // than 18 tiles (max_disp > 272) or a tile does not fit LDS; the dispatcher in capi.hip then
 // uses the row-tile kernel.  allow_compact = 0 pins the dense path (A/B benchmarks, tests).
+// mbits = 1: rmask / tmask point at bit-packed masks ([B,H,ceil(W/64)] 64-bit words, decnet_detail_mask's layout).
 int decnet_mfma_forward(int mode, const float *ref, const float *tar, const float *rmask,
                         const float *tmask, const float *disparity, float *out, float *var_out,
                         float *sum_sim, float *max_cost, int B, int C, int H, int W, int max_disp,
-                        int allow_compact, hipStream_t stream) {
+                        int allow_compact, int mbits, hipStream_t stream) {
     const int D = max_disp;
     const int need = D <= 1 ? 1 : (D - 1 + 15) / 16 + 1;
 #define GO(N)                                                                                     \
     return launch_kq<N>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, \
-                        B, C, H, W, D, allow_compact, stream)
+                        B, C, H, W, D, allow_compact, mbits, stream)
 #ifdef DECNET_DEV_STAGE3
     if (need <= 15 && need > 11) GO(15);
     return DECNET_ERR_UNSUPPORTED;

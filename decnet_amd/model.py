@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import spamatvar_forward
+from .ops import spamatvar_forward, spamatvar_forward_bits
 from .stage0 import CostRegNetNoDown, Stage0
 
 
@@ -429,24 +429,28 @@ class GenerateSparseMask(nn.Module):
             self._hp_key = key
         return self._hp
 
-    def mask(self, cur, pre, thold):
+    def mask(self, cur, pre, thold, want_bits=False):
         """``(sigmoid(self(cur, pre)) > thold)`` as a float 0/1 plane [B,H,W] (SparseDenseNetRefinementMask.py:
         148-170).  On the GPU in eval mode the squared difference, both convolutions of ``conv``, the sigmoid
         and the threshold are one kernel (csrc/maskgen.hip)."""
         if (self.training or not cur.is_cuda or cur.dtype != torch.float32 or torch.is_grad_enabled() or
                 os.environ.get("DECNET_CONV2D", "hip") != "hip" or cur.shape[-2] > 65535):
-            return (torch.sigmoid(self(cur, pre)) > thold).to(cur.dtype)
+            m = (torch.sigmoid(self(cur, pre)) > thold).to(cur.dtype)
+            return (m, None) if want_bits else m
         from . import _lib
         from .ops import _stream
         a, b = self.conv_sub(cur).contiguous(), self.deconv(pre).contiguous()
         B, _, H, W = a.shape
         w3, s3, b3, w1, s1, b1 = self._host_params()
         out = torch.empty((B, H, W), dtype=torch.float32, device=a.device)
+        # want_bits: also the bit-packed copy the SpaMat kernels read (64 pixels per int64 word)
+        bits = torch.empty((B, H, (W + 63) // 64), dtype=torch.int64, device=a.device) if want_bits else None
         with torch.cuda.device(a.device):
             _lib.check(_lib.lib().decnet_detail_mask(a.data_ptr(), b.data_ptr(), w3, s3, b3, w1, s1, b1, float(thold),
-                                                     out.data_ptr(), None, None, B, H, W, _stream(a)),
+                                                     out.data_ptr(), None, bits.data_ptr() if want_bits else None,
+                                                     B, H, W, _stream(a)),
                        "decnet_detail_mask")
-        return out
+        return (out, bits) if want_bits else out
 
 
 class DynamicUpsampling(nn.Module):
@@ -620,15 +624,21 @@ class SparseDenseNetRefinementMask(nn.Module):
                 continue
             if self.use_detail:                                           # reference :148-170
                 gen = self.detail_detection[stage - 1]
-                lmask = gen.mask(L, pre_L, self.thold)
-                rmask = gen.mask(R, pre_R, self.thold)
+                lmask, lbits = gen.mask(L, pre_L, self.thold, want_bits=True)
+                rmask, rbits = gen.mask(R, pre_R, self.thold, want_bits=True)
                 pre_L, pre_R = L, R
             else:
                 lmask, rmask = left_mask_list[stage - 1], right_mask_list[stage - 1]
+                lbits = rbits = None
             dense = self.dynamic_upsampling[stage - 1](pred, L)           # reference :178
-            # SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch
-            sparse, var, _, _ = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(),
-                                                  rmask.contiguous(), cur_max_disp)
+            # SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch; the masks as the bit-packed
+            # copies the mask kernel wrote where there are any (the float planes stay what SoftAttention reads)
+            if (lbits is not None and rbits is not None and cur_max_disp <= 272 and
+                    os.environ.get("DECNET_SPAMAT_BITS", "1") == "1"):
+                sparse, var, _, _ = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, cur_max_disp)
+            else:
+                sparse, var, _, _ = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(),
+                                                      rmask.contiguous(), cur_max_disp)
             soft = self.soft_attention[stage - 1](
                 (L, dense.unsqueeze(1), sparse.unsqueeze(1), lmask.unsqueeze(1), -var.unsqueeze(1))).squeeze(1)
             fused = dense * (1 - soft) + soft * sparse                    # reference :202

@@ -149,6 +149,35 @@ def spavar_backward(ref, tar, rmask, tmask, disparity, output, sum_sim, max_cost
     _lib.check(rc, "decnet_spavar_backward")
 
 
+def spamatvar_forward_bits(ref, tar, rbits, tbits, max_disp, out=None):
+    """spamatvar_forward with bit-packed masks: rbits / tbits int64 [B,H,ceil(W/64)], bit i of word w of a row = pixel
+    64 w + i (what ``decnet_detail_mask`` writes beside the float plane).  Same results as the float-mask call."""
+    _chk("ref_feas", ref)
+    if ref.dim() != 4:
+        raise ValueError("ref_feas must be [B,C,H,W]")
+    B, C, H, W = ref.shape
+    _chk("tar_feas", tar, (B, C, H, W))
+    for n, t in (("ref_bits", rbits), ("tar_bits", tbits)):
+        if (not isinstance(t, torch.Tensor) or t.dtype != torch.int64 or not t.is_contiguous() or
+                tuple(t.shape) != (B, H, (W + 63) // 64)):
+            raise ValueError("%s must be a contiguous int64 tensor [B,H,ceil(W/64)]" % n)
+    _same_device(ref, tar, rbits, tbits)
+    D = int(max_disp)
+    if D < 1:
+        raise ValueError("max_disp must be >= 1")
+    if out is None:
+        out = tuple(torch.empty((B, H, W), dtype=torch.float32, device=ref.device) for _ in range(4))
+    o, v, s, m = out
+    for n, t in (("output", o), ("variance", v), ("sum_similarities", s), ("max_cost", m)):
+        _chk(n, t, (B, H, W))
+    with _on_device(ref):
+        rc = _fn("decnet_spamatvar_forward_bits")(
+            ref.data_ptr(), tar.data_ptr(), rbits.data_ptr(), tbits.data_ptr(), o.data_ptr(),
+            v.data_ptr(), s.data_ptr(), m.data_ptr(), B, C, H, W, D, _stream(ref))
+    _lib.check(rc, "decnet_spamatvar_forward_bits")
+    return o, v, s, m
+
+
 def spamatvar_forward(ref, tar, rmask, tmask, max_disp, out=None):
     """Fused SpaMat + SpaVar forward (the model's only use of SpaVar,
     SparseDenseNetRefinementMask.py:183-192).  Returns (disparity, variance, sum_sim, max_cost),

@@ -91,6 +91,14 @@ int decnet_spamatvar_forward(const float *ref, const float *tar, const float *re
                              const float *tar_mask, float *output, float *variance,
                              float *sum_similarities, float *max_cost, int B, int C, int H,
                              int W, int max_disp, void *stream);
+/* decnet_spamatvar_forward with bit-packed masks: ref_bits / tar_bits [B,H,ceil(W/64)] 64-bit words, bit i of word w
+ * of a row = pixel 64 w + i, zero past W (what decnet_detail_mask writes beside the float plane of the reference's
+ * contract).  Same results as the float-mask call; 8 of the pass's 88 bytes per pixel (C = 8) are not read.
+ * DECNET_ERR_UNSUPPORTED above max_disp 272 (no bit-mask variant of the row-tile fallback). */
+int decnet_spamatvar_forward_bits(const float *ref, const float *tar, const unsigned long long *ref_bits,
+                                  const unsigned long long *tar_bits, float *output, float *variance,
+                                  float *sum_similarities, float *max_cost, int B, int C, int H, int W,
+                                  int max_disp, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Stage 0 (coarsest level): dense cost volume -> 3-D conv aggregation -> soft-argmax.

@@ -353,3 +353,51 @@ def test_large_and_small_magnitudes(dev, C, W, D, scale, relu):
         err = np.abs(fo.cpu().numpy() - o)
         assert np.median(err) < 1e-4 and err.mean() < (2e-3 if scale > 1 else 1e-4), (dens, err.mean(), err.max())
         np.testing.assert_allclose(fs.cpu().numpy(), s, rtol=2e-3 if scale > 1 else 2e-5, atol=1e-9)
+
+
+def pack_mask_bits(mask):
+    """float 0/1 [B,H,W] -> int64 [B,H,ceil(W/64)], bit i of word w = pixel 64 w + i (decnet_detail_mask's layout)."""
+    B, H, W = mask.shape
+    wpr = (W + 63) // 64
+    m = np.zeros((B, H, wpr * 64), dtype=np.uint64)
+    m[:, :, :W] = (mask.cpu().numpy() != 0)
+    words = (m.reshape(B, H, wpr, 64) << np.arange(64, dtype=np.uint64)).sum(-1, dtype=np.uint64)
+    return torch.from_numpy(words.view(np.int64))
+
+
+@pytest.mark.parametrize("C,H,W,D", [(8, 12, 972, 216), (8, 12, 1242, 216), (24, 12, 324, 72), (72, 5, 108, 24),
+                                     (8, 3, 61, 40), (12, 4, 130, 100), (8, 12, 1512, 270)])
+def test_fused_forward_with_bit_packed_masks_equals_float_masks(dev, C, H, W, D):
+    """decnet_spamatvar_forward_bits (masks as 64 pixels per word, what decnet_detail_mask writes) against the
+    float-mask call on rows of every kind (sparse-row kernel, hand-over, dense, compact, empty): bit for bit."""
+    import decnet_amd
+    g = torch.Generator().manual_seed(C * 1000 + W)
+    L = torch.relu(torch.randn(1, C, H, W, generator=g))
+    R = torch.relu(torch.randn(1, C, H, W, generator=g))
+    dens = [(0.02, 0.02), (1.0, 1.0), (0.1, 0.1), (0.5, 0.5), (0.05, 0.9), (0.9, 0.05), (0.2, 0.2),
+            (0.0, 0.3), (0.3, 0.0), (0.26, 0.26), (0.03, 0.03), (0.4, 0.6)][:H]
+    rm = torch.stack([(torch.rand(W, generator=g) < p).float() for p, _ in dens]).view(1, H, W)
+    tm = torch.stack([(torch.rand(W, generator=g) < p).float() for _, p in dens]).view(1, H, W)
+    dL, dR, drm, dtm = (t.to(dev) for t in (L, R, rm, tm))
+    want = decnet_amd.spamatvar_forward(dL, dR, drm, dtm, D)
+    got = decnet_amd.spamatvar_forward_bits(dL, dR, pack_mask_bits(rm).to(dev), pack_mask_bits(tm).to(dev), D)
+    for a, b_, name in zip(got, want, ("output", "variance", "sum_similarities", "max_cost")):
+        assert torch.equal(a, b_), name
+    with pytest.raises(ValueError):
+        decnet_amd.spamatvar_forward_bits(dL, dR, drm, dtm, D)            # float planes are not bit words
+
+
+def test_mask_kernel_bits_feed_the_bit_mask_call(dev):
+    """GenerateSparseMask.mask(want_bits=True): the bit-packed copy is the float plane, and the model's forward is the
+    same with DECNET_SPAMAT_BITS=0 (float planes into SpaMat) and 1 (bits)."""
+    from decnet_amd.model import GenerateSparseMask
+    torch.manual_seed(3)
+    gen = GenerateSparseMask(8, 3).to(dev).eval()
+    cur, pre = torch.randn(2, 8, 66, 135, device=dev), torch.randn(2, 24, 22, 45, device=dev)
+    with torch.no_grad():
+        z = gen(cur, pre)
+        thold = float(torch.sigmoid(z).median())
+        m, bits = gen.mask(cur, pre, thold, want_bits=True)
+    assert bits is not None and bits.dtype == torch.int64 and tuple(bits.shape) == (2, 66, 3)
+    assert torch.equal(pack_mask_bits(m), bits.cpu())
+    assert 0.2 < float(m.mean()) < 0.8

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shape", type=str, default=None, help="C,H,W,D override")
+    ap.add_argument("--bits", action="store_true", help="fused mode with bit-packed masks (decnet_spamatvar_forward_bits)")
     a = ap.parse_args()
     C, H, W, D = SHAPES[a.stage] if a.shape is None else map(int, a.shape.split(","))
     B = a.batch
@@ -39,8 +40,19 @@ def main():
     outs = [torch.empty(B, H, W, device=dev) for _ in range(4)]
     mu = torch.rand(B, H, W, device=dev) * D
 
+    if a.bits:
+        def pack(m):                                      # 64 pixels per int64 word, bit i = pixel 64 w + i
+            wpr = (W + 63) // 64
+            z = torch.zeros(B, H, wpr * 64, dtype=torch.int64, device=dev)
+            z[:, :, :W] = (m != 0).long()
+            sh = torch.arange(64, device=dev, dtype=torch.int64)
+            return (z.view(B, H, wpr, 64) << sh).sum(-1)   # two's complement wrap of bit 63 is the bit pattern wanted
+        rb, tb = pack(rm).contiguous(), pack(tm).contiguous()
+
     def run():
-        if a.mode == "fused":
+        if a.bits:
+            decnet_amd.spamatvar_forward_bits(L, R, rb, tb, D, out=tuple(outs))
+        elif a.mode == "fused":
             decnet_amd.spamatvar_forward(L, R, rm, tm, D, out=tuple(outs))
         elif a.mode == "mat":
             ops.spamat_forward(L, R, rm, tm, outs[0], outs[2], outs[3], D)

@@ -24,6 +24,14 @@ for d in 0.10 0.05 0.02; do
   cd $R
   python3 tools/pmc_kernels.py $O/pmc_sf_$d $O/pmc_sw_$d $O/${TAG}_pmc_extra_raw.json $O/traffic.json "spamat_fused_stage3_density_$d=spamat_fwd_sparse<15+spamat_fwd_mfma<15"
 done
+# the same with bit-packed masks (decnet_spamatvar_forward_bits)
+for d in 0.10 0.05; do
+  cd /tmp
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bsf_$d -o f -- python3 $R/tools/bench_spamat.py --stage 3 --density $d --iters 5 --bits > /dev/null 2> $O/pmc_bsf_$d.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bsw_$d -o w -- python3 $R/tools/bench_spamat.py --stage 3 --density $d --iters 5 --bits > /dev/null 2> $O/pmc_bsw_$d.err
+  cd $R
+  python3 tools/pmc_kernels.py $O/pmc_bsf_$d $O/pmc_bsw_$d $O/${TAG}_pmc_extra_raw.json $O/traffic.json "spamat_fused_bits_stage3_density_$d=spamat_fwd_sparse<15+spamat_fwd_mfma<15"
+done
 # the stage-3 backward of config 5 (B = 4): both gradient launches
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bf -o f -- python3 $R/tools/bench_spamat_bwd.py --stage 3 --batch 4 --iters 5 > /dev/null 2> $O/pmc_bf.err
