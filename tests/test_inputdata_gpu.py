@@ -32,10 +32,12 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden", "inputdata")
 sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
 
 CASES = [("Sceneflow", "0006", "init17"), ("KITTI", "000009_10", "init17"), ("real", "00003", "init17"),
          ("real", "00004", "init17"), ("Sceneflow", "0006", "fill"), ("KITTI", "000009_10", "fill")]
 from flipmap import dirty_map  # noqa: E402
+from spy_util import spamat_spy  # noqa: E402
 
 
 def _unpack(d, key):
@@ -71,26 +73,22 @@ def test_inputdata_pair_matches_reference_graph(ds_name, name, variant):
     model = model.to(dev).eval()
 
     rec, preds = {}, {}
-    orig = M.spamatvar_forward
 
-    def spy(L, R, lm, rm, D):
-        o = orig(L, R, lm, rm, D)
+    def spy(L, R, lm, rm, D, o):
         i = len(rec) + 1
         rec[i] = (lm[0].cpu().numpy() != 0, rm[0].cpu().numpy() != 0, o[0][0].cpu().numpy(), int(D))
-        return o
     hooks = [model.refinement[i].register_forward_hook(
         lambda m, inp, out, i=i: preds.__setitem__(i + 1, out[0][0].cpu().numpy())) for i in range(3)]
     hooks.append(model.register_forward_hook(lambda m, inp, out: preds.__setitem__("final", out[-1][0].cpu().numpy())))
     reg = model.cost_regularizer
     stage0 = reg.stage0
     reg.stage0 = lambda *a, **k: preds.setdefault(0, stage0(*a, **k))
-    M.spamatvar_forward = spy
     try:
         pdir = os.path.join(GOLD, ds_name, name)
         limg, rimg = demo.read_rgb(os.path.join(pdir, "im0.png")), demo.read_rgb(os.path.join(pdir, "im1.png"))
-        png, _ = demo.run_pair(model, limg, rimg, dev, demo.read_ndisp(os.path.join(pdir, "calib.txt")))
+        with spamat_spy(spy):
+            png, _ = demo.run_pair(model, limg, rimg, dev, demo.read_ndisp(os.path.join(pdir, "calib.txt")))
     finally:
-        M.spamatvar_forward = orig
         del reg.stage0
         for h in hooks:
             h.remove()

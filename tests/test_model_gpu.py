@@ -18,6 +18,7 @@ import torch
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
 
 
 def test_e2e_against_reference_graph():
@@ -35,20 +36,13 @@ def test_e2e_against_reference_graph():
     left, right = e2e_inputs()
     assert abs(left.double().sum().item() + right.double().abs().sum().item() - float(d["input_checksum"])) < 1e-9
     rec = {}
-    import decnet_amd.model as M
-    orig = M.spamatvar_forward
+    from spy_util import spamat_spy
 
-    def spy(L, R, lm, rm, D):
-        o = orig(L, R, lm, rm, D)
+    def spy(L, R, lm, rm, D, o):
         rec[len(rec) // 2 + 1] = (lm.cpu().numpy(), o[0].cpu().numpy())
         rec[-(len(rec) // 2 + 1)] = None
-        return o
-    M.spamatvar_forward = spy
-    try:
-        with torch.no_grad():
-            pred = model(left.to(dev), right.to(dev))[-1].cpu().numpy()
-    finally:
-        M.spamatvar_forward = orig
+    with spamat_spy(spy), torch.no_grad():
+        pred = model(left.to(dev), right.to(dev))[-1].cpu().numpy()
     stages = sorted(k for k in rec if k > 0)
     assert stages == [1, 2, 3]
     flip_any = np.zeros(d["pred"].shape[-2:], bool)
