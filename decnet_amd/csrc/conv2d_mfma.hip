@@ -489,20 +489,20 @@ int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shi
     const int tail8 = cin - 16 * (nchunk - 1) <= 8;              // the last chunk's channels 8-15 are padding
     const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 4 * TM);
     const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(NT / TN), (unsigned)B);
-    static bool attr = false;                                  // idempotent; a race sets the same value twice
+    // more than 64 KiB of dynamic LDS needs the attribute; set per launch (it is per device, and cheap)
     if constexpr (PC) {
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)conv2d_mfma_pc<TM, TN, NU>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, DECNET_LDS_BYTES);
-            attr = true;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)conv2d_mfma_pc<TM, TN, NU>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL((conv2d_mfma_pc<TM, TN, NU>), grid, dim3(2 * THREADS), lds, stream, in, wp, scale, shift, y,
                            Cout, H, W, KT, dil, relu, nchunk, NT, tiles_x, tail8);
     } else {
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)conv2d_mfma<TM, TN, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      DECNET_LDS_BYTES);
-            attr = true;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)conv2d_mfma<TM, TN, NU>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL((conv2d_mfma<TM, TN, NU>), grid, dim3(THREADS), lds, stream, in, wp, scale, shift, y, Cout, H,
                            W, KT, dil, relu, nchunk, NT, tiles_x, tail8);
