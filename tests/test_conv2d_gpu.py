@@ -77,6 +77,31 @@ def test_mfma_conv_unit_vs_torch_cpu(dev, monkeypatch, cins, cout, k, dil, relu,
             assert float((got.double() - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max())), pc
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_mfma_conv_random_shapes(dev, seed):
+    """Seeded random layer shapes (channel counts that are not multiples of anything, images smaller than a tile, one
+    to four concatenated inputs, every dilation the kernel takes) through the kernel's own dispatch."""
+    import random
+    rnd = random.Random(1234 + seed)
+    nseg = rnd.choice((1, 1, 2, 3, 4))
+    cins = tuple(rnd.choice((1, 3, 7, 8, 16, 17, 24, 31, 40, 65)) for _ in range(nseg))
+    cout = rnd.choice((1, 5, 16, 17, 24, 33, 49, 64, 81, 97, 130))
+    k = rnd.choice((1, 3, 3, 3))
+    dil = rnd.choice((1, 1, 2, 3, 4)) if k == 3 else 1
+    B, H, W = rnd.choice((1, 2, 3)), rnd.choice((1, 5, 16, 23, 40, 67)), rnd.choice((3, 15, 16, 17, 50, 129))
+    cin = sum(cins)
+    u = _unit(cin, cout, k, dil, rnd.random() < 0.7, rnd.random() < 0.7, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    with torch.no_grad():
+        ref = u.double()(torch.cat(xs, 1).double())
+        ud = u.float().to(dev)
+        xd = [t.to(dev) for t in xs]
+        got = ud._forward_mfma(xd if len(xd) > 1 else xd[0]).cpu()
+    assert got.shape == ref.shape
+    assert float((got.double() - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max())), (cins, cout, k, dil, B, H, W)
+
+
 def test_mfma_conv_is_what_the_many_channel_units_run(dev):
     u = _unit(72, 72, 3).to(dev)
     x = torch.randn(2, 72, 60, 108, device=dev)
