@@ -44,6 +44,9 @@ SIGNATURES = {
     "decnet_conv2d_mfma_packed_bytes": [_I] * 3,
     "decnet_conv2d_mfma_pack_weight": [_P, _P] + [_I] * 3 + [_P],
     "decnet_conv2d_mfma_cat_bn_act": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P],
+    "decnet_deconv2d_mfma_packed_bytes": [_I] * 2,
+    "decnet_deconv2d_mfma_pack_weight": [_P, _P] + [_I] * 2 + [_P],
+    "decnet_deconv2d_mfma_k3s3_bn_act": [_P] * 5 + [_I] * 6 + [_P],
     "decnet_warp_disparity": [_P, _P, _P] + [_I] * 4 + [_P],
     "decnet_dynamic_upsample3": [_P, _P, _P] + [_I] * 3 + [_P],
     "decnet_tapconv_chunk_floats": [_I] * 4,

@@ -60,8 +60,9 @@ __device__ __forceinline__ void split3(float x, int &h, int &m, int &l) {
 }
 
 // w [Cout][Cin][KT] -> wp[chunk][tap][j][n tile][lane] (16 bytes: the lane's 8 bf16 of the B operand)
+// tr: w is a ConvTranspose2d weight [Cin][Cout / 9][3][3] read as the 1 x 1 convolution to n = 9 co + 3 ky + kx
 __global__ void conv2d_mfma_pack(const float *__restrict__ w, i32x4 *__restrict__ wp, int Cin, int Cout, int KT,
-                                 int NT, long total) {
+                                 int NT, long total, int tr) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int lane = (int)(idx & 63);
@@ -77,7 +78,7 @@ __global__ void conv2d_mfma_pack(const float *__restrict__ w, i32x4 *__restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = 16 * ck + 8 * grp + e;
-        const float v = (n < Cout && c < Cin) ? w[((size_t)n * Cin + c) * KT + tap] : 0.f;
+        const float v = (n < Cout && c < Cin) ? (tr ? w[(size_t)c * Cout + n] : w[((size_t)n * Cin + c) * KT + tap]) : 0.f;
         int h, m, l;
         split3(v, h, m, l);
         t[e] = term == 0 ? h : term == 1 ? m : l;
@@ -88,12 +89,69 @@ __global__ void conv2d_mfma_pack(const float *__restrict__ w, i32x4 *__restrict_
     wp[idx] = o;
 }
 
+// Epilogue of both kernels: the lane holds output channel n = tile * 16 + r of the pixels x0 + 4 q .. + 3 of TM rows.
+// shuf = 0: y [B,Cout,H,W] = act(acc * scale[n] + shift[n]).  shuf = C (transposed convolution k = 3, stride 3, as a
+// 1 x 1 convolution to 9 C channels n = 9 co + 3 ky + kx): y [B,C,3H,3W] at (3 row + ky, 3 x + kx), scale / shift per co.
+template <int TM, int TN>
+__device__ __forceinline__ void conv2d_mfma_store(const f32x4 (&acc)[TM][TN], const float *__restrict__ scale,
+                                                  const float *__restrict__ shift, float *__restrict__ y, int b, int Cout,
+                                                  int H, int W, int relu, int nt0, int r, int q, int x0, int row0,
+                                                  int shuf) {
+    const size_t HW = (size_t)H * W;
+    const int xq = x0 + 4 * q;
+    const bool vec = (W & 3) == 0 && xq + 3 < W;
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int n = (nt0 + nt) * 16 + r;
+        if (n >= Cout) continue;
+        if (shuf) {
+            const int co = n / 9, kk = n - 9 * co, ky = kk / 3, kx = kk - 3 * ky;
+            const float sc = scale[co], sh = shift[co];
+            float *yp = y + ((size_t)b * shuf + co) * 9 * HW;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int row = row0 + mt;
+                if (row >= H) break;
+                float *dst = yp + ((size_t)(3 * row + ky) * 3 * W) + kx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = fmaf(acc[mt][nt][i], sc, sh);
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (xq + i < W) dst[3 * (xq + i)] = v;
+                }
+            }
+            continue;
+        }
+        const float sc = scale[n], sh = shift[n];
+        float *yp = y + ((size_t)b * Cout + n) * HW;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int row = row0 + mt;
+            if (row >= H) break;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = fmaf(v[i], sc, sh);
+                if (relu) v[i] = fmaxf(v[i], 0.f);
+            }
+            float *dst = yp + (size_t)row * W + xq;
+            if (vec) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xq + i < W) dst[i] = v[i];
+            }
+        }
+    }
+}
+
 // NU: staging units per thread, 128 NU >= pixels of the halo tile
 template <int TM, int TN, int NU>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
     Segs in, const i32x4 *__restrict__ wp, const float *__restrict__ scale, const float *__restrict__ shift,
     float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x,
-    int tail8) {
+    int tail8, int shuf) {
     constexpr int TH = 4 * TM;
     extern __shared__ i32x4 smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -228,36 +286,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
         }
     }
 
-    // ---- epilogue: lane holds output channel n = tile * 16 + r, pixels x0 + 4 q .. + 3 of each row ----
-    if (!wave_active) return;
-    const int xq = x0 + 4 * q;
-    const bool vec = (W & 3) == 0 && xq + 3 < W;
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        const int n = (nt0 + nt) * 16 + r;
-        if (n >= Cout) continue;
-        const float sc = scale[n], sh = shift[n];
-        float *yp = y + ((size_t)b * Cout + n) * HW;
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int row = y0 + rowbase + mt;
-            if (row >= H) break;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = fmaf(v[i], sc, sh);
-                if (relu) v[i] = fmaxf(v[i], 0.f);
-            }
-            float *dst = yp + (size_t)row * W + xq;
-            if (vec) {
-                *reinterpret_cast<f32x4 *>(dst) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (xq + i < W) dst[i] = v[i];
-            }
-        }
-    }
+    if (wave_active)
+        conv2d_mfma_store<TM, TN>(acc, scale, shift, y, b, Cout, H, W, relu, nt0, r, q, x0, y0 + rowbase, shuf);
 }
 
 // ---- producer / consumer variant (TN >= 4) ---------------------------------------------------------------------------
@@ -272,7 +302,7 @@ template <int TM, int TN, int NU>
 __global__ __launch_bounds__(2 * THREADS, 1) void conv2d_mfma_pc(
     Segs in, const i32x4 *__restrict__ wp, const float *__restrict__ scale, const float *__restrict__ shift,
     float *__restrict__ y, int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int tiles_x,
-    int tail8) {
+    int tail8, int shuf) {
     constexpr int TH = 4 * TM;
     extern __shared__ i32x4 smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -422,36 +452,8 @@ __global__ __launch_bounds__(2 * THREADS, 1) void conv2d_mfma_pc(
         __syncthreads();                                       // barrier ck + 1
     }
 
-    // ---- epilogue: lane holds output channel n = tile * 16 + r, pixels x0 + 4 q .. + 3 of each row ----
-    if (!wave_active) return;
-    const int xq = x0 + 4 * q;
-    const bool vec = (W & 3) == 0 && xq + 3 < W;
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        const int n = (nt0 + nt) * 16 + r;
-        if (n >= Cout) continue;
-        const float sc = scale[n], sh = shift[n];
-        float *yp = y + ((size_t)b * Cout + n) * HW;
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int row = y0 + rowbase + mt;
-            if (row >= H) break;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = fmaf(v[i], sc, sh);
-                if (relu) v[i] = fmaxf(v[i], 0.f);
-            }
-            float *dst = yp + (size_t)row * W + xq;
-            if (vec) {
-                *reinterpret_cast<f32x4 *>(dst) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (xq + i < W) dst[i] = v[i];
-            }
-        }
-    }
+    if (wave_active)
+        conv2d_mfma_store<TM, TN>(acc, scale, shift, y, b, Cout, H, W, relu, nt0, r, q, x0, y0 + rowbase, shuf);
 }
 
 // Rows per wave.  A launch costs (rounds of resident workgroups) x (TM + a fixed share for prologue, staging and
@@ -480,7 +482,7 @@ inline int pick_tm(int B, int H, int W, int nchunkN, int tn, int pad, bool pc) {
 
 template <int TM, int TN, int NU, bool PC>
 int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shift, float *y, int B, int Cout, int H,
-           int W, int KT, int dil, int relu, int nchunk, int NT, hipStream_t stream) {
+           int W, int KT, int dil, int relu, int nchunk, int NT, int shuf, hipStream_t stream) {
     const int pad = KT == 9 ? dil : 0;
     const size_t lds = (size_t)(16 + 2 * pad) * (4 * TM + 2 * pad) * 6 * 16 * (PC ? 2 : 1);
     if (lds > DECNET_LDS_BYTES) return DECNET_ERR_UNSUPPORTED;
@@ -497,7 +499,7 @@ int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shi
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL((conv2d_mfma_pc<TM, TN, NU>), grid, dim3(2 * THREADS), lds, stream, in, wp, scale, shift, y,
-                           Cout, H, W, KT, dil, relu, nchunk, NT, tiles_x, tail8);
+                           Cout, H, W, KT, dil, relu, nchunk, NT, tiles_x, tail8, shuf);
     } else {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)conv2d_mfma<TM, TN, NU>,
@@ -505,7 +507,7 @@ int launch(const Segs &in, const i32x4 *wp, const float *scale, const float *shi
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL((conv2d_mfma<TM, TN, NU>), grid, dim3(THREADS), lds, stream, in, wp, scale, shift, y, Cout, H,
-                           W, KT, dil, relu, nchunk, NT, tiles_x, tail8);
+                           W, KT, dil, relu, nchunk, NT, tiles_x, tail8, shuf);
     }
     return decnet_launch_status();
 }
@@ -515,9 +517,9 @@ inline int tile_pixels(int tm, int pad) { return (16 + 2 * pad) * (4 * tm + 2 * 
 
 template <int TN, bool PC>
 int launch_tm(int tm, const Segs &in, const i32x4 *wp, const float *scale, const float *shift, float *y, int B,
-              int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, hipStream_t stream) {
+              int Cout, int H, int W, int KT, int dil, int relu, int nchunk, int NT, int shuf, hipStream_t stream) {
     const int pad = KT == 9 ? dil : 0;
-#define ARGS in, wp, scale, shift, y, B, Cout, H, W, KT, dil, relu, nchunk, NT, stream
+#define ARGS in, wp, scale, shift, y, B, Cout, H, W, KT, dil, relu, nchunk, NT, shuf, stream
     if (pad <= 1) {
         if constexpr (fits(8, TN, PC)) {
             if (tm == 8) return launch<8, TN, 5, PC>(ARGS);
@@ -546,7 +548,7 @@ size_t decnet_conv2d_mfma_packed_bytes(int Cin, int Cout, int k) {
     return blocks * padded_nt(Cout) * 64 * 16;
 }
 
-int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream) {
+static int pack_impl(const float *w, void *w_packed, int Cin, int Cout, int k, int tr, void *stream) {
     if (!w || !w_packed) return DECNET_ERR_NULL_POINTER;
     const size_t bytes = decnet_conv2d_mfma_packed_bytes(Cin, Cout, k);
     if (!bytes) return DECNET_ERR_UNSUPPORTED;
@@ -556,8 +558,51 @@ int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int 
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(conv2d_mfma_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       (i32x4 *)w_packed, Cin, Cout, k * k, NT, total);
+                       (i32x4 *)w_packed, Cin, Cout, k * k, NT, total, tr);
     return decnet_launch_status();
+}
+
+int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream) {
+    return pack_impl(w, w_packed, Cin, Cout, k, 0, stream);
+}
+
+size_t decnet_deconv2d_mfma_packed_bytes(int Cin, int Cout) {
+    if (Cout < 1 || Cout > 7281) return 0;
+    return decnet_conv2d_mfma_packed_bytes(Cin, 9 * Cout, 1);
+}
+
+int decnet_deconv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, void *stream) {
+    if (Cout < 1 || Cout > 7281) return DECNET_ERR_UNSUPPORTED;
+    return pack_impl(w, w_packed, Cin, 9 * Cout, 1, 1, stream);
+}
+
+static int run_impl(const Segs &in, long Cin, const void *w_packed, const float *scale, const float *shift, float *y,
+                    int B, int Cout, int H, int W, int k, int dilation, int relu, int shuf, void *stream) {
+    if (B > 65535 || Cin > 65536 || (double)H * W >= 2147483648.0 / (shuf ? 9 : 1)) return DECNET_ERR_UNSUPPORTED;
+    const int TN = pick_tn(Cout), NT = padded_nt(Cout), nchunk = ceil_div((int)Cin, 16);
+    if (NT / TN > 65535 || (double)ceil_div(W, 16) * ceil_div(H, 8) >= 2.0e9) return DECNET_ERR_UNSUPPORTED;
+    // the 4-wave kernel (two workgroups per CU) when its grid fills the chip at least once, else the 8-wave
+    // producer / consumer kernel (TN >= 4: measured 217 -> 81 at 60 x 108, 448 workgroups: 0.156 vs 0.104 ms;
+    // 81 -> 81 at 180 x 324, 1512 workgroups: 0.371 vs 0.390 ms)
+    const int pad = k == 3 ? dilation : 0;
+    int tm = pick_tm(B, H, W, NT / TN, TN, pad, false);
+    const char *env = getenv("DECNET_CONV2D_MFMA_PC");                      // tests / experiments: 0 / 1 pins the kernel
+    bool pc = TN >= 4 && (double)ceil_div(W, 16) * ceil_div(H, 4 * tm) * B * (NT / TN) <= 512.0;
+    if (env && TN >= 4) pc = atoi(env) != 0;
+    if (pc) tm = pick_tm(B, H, W, NT / TN, TN, pad, true);
+    const i32x4 *wp = (const i32x4 *)w_packed;
+    hipStream_t st = (hipStream_t)stream;
+#define GO(T, P) \
+    return launch_tm<T, P>(tm, in, wp, scale, shift, y, B, Cout, H, W, k * k, dilation, relu, nchunk, NT, shuf, st)
+    switch (TN) {
+        case 2: GO(2, false);
+        case 3: GO(3, false);
+        case 4: if (pc) GO(4, true); else GO(4, false);
+        case 5: if (pc) GO(5, true); else GO(5, false);
+        case 6: if (pc) GO(6, true); else GO(6, false);
+    }
+#undef GO
+    return DECNET_ERR_UNSUPPORTED;
 }
 
 int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int nseg, const void *w_packed,
@@ -576,30 +621,19 @@ int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int n
         Cin += cins[i];
     }
     in.n = nseg;
-    if (B > 65535 || Cin > 65536 || (double)H * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;
-    const int TN = pick_tn(Cout), NT = padded_nt(Cout), nchunk = ceil_div((int)Cin, 16);
-    if (NT / TN > 65535 || (double)ceil_div(W, 16) * ceil_div(H, 8) >= 2.0e9) return DECNET_ERR_UNSUPPORTED;
-    // the 4-wave kernel (two workgroups per CU) when its grid fills the chip at least once, else the 8-wave
-    // producer / consumer kernel (TN >= 4: measured 217 -> 81 at 60 x 108, 448 workgroups: 0.156 vs 0.104 ms;
-    // 81 -> 81 at 180 x 324, 1512 workgroups: 0.371 vs 0.390 ms)
-    const int pad = k == 3 ? dilation : 0;
-    int tm = pick_tm(B, H, W, NT / TN, TN, pad, false);
-    const char *env = getenv("DECNET_CONV2D_MFMA_PC");                      // tests / experiments: 0 / 1 pins the kernel
-    bool pc = TN >= 4 && (double)ceil_div(W, 16) * ceil_div(H, 4 * tm) * B * (NT / TN) <= 512.0;
-    if (env && TN >= 4) pc = atoi(env) != 0;
-    if (pc) tm = pick_tm(B, H, W, NT / TN, TN, pad, true);
-    const i32x4 *wp = (const i32x4 *)w_packed;
-    hipStream_t st = (hipStream_t)stream;
-#define GO(T, P) return launch_tm<T, P>(tm, in, wp, scale, shift, y, B, Cout, H, W, k * k, dilation, relu, nchunk, NT, st)
-    switch (TN) {
-        case 2: GO(2, false);
-        case 3: GO(3, false);
-        case 4: if (pc) GO(4, true); else GO(4, false);
-        case 5: if (pc) GO(5, true); else GO(5, false);
-        case 6: if (pc) GO(6, true); else GO(6, false);
-    }
-#undef GO
-    return DECNET_ERR_UNSUPPORTED;
+    return run_impl(in, Cin, w_packed, scale, shift, y, B, Cout, H, W, k, dilation, relu, 0, stream);
+}
+
+int decnet_deconv2d_mfma_k3s3_bn_act(const float *x, const void *w_packed, const float *scale, const float *shift,
+                                     float *y, int B, int Cin, int Cout, int H, int W, int relu, void *stream) {
+    if (!x || !w_packed || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
+    if (Cout > 7281) return DECNET_ERR_UNSUPPORTED;
+    Segs in{};
+    in.p[0] = x;
+    in.c[0] = Cin;
+    in.n = 1;
+    return run_impl(in, Cin, w_packed, scale, shift, y, B, 9 * Cout, H, W, 1, 1, relu, Cout, stream);
 }
 
 }  // extern "C"

@@ -60,6 +60,13 @@ class Unit(nn.Module):
                 c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and x.shape[-1] * x.shape[-2] >= 4096 and
                 c.dilation[0] <= 4 and os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma"
+        # transposed convolution k = 3, stride 3 with more than 8 output channels: the same kernel, as a 1 x 1 convolution
+        # to 9 Cout channels with a pixel-shuffle store
+        if (isinstance(c, nn.ConvTranspose2d) and c.out_channels > 8 and c.in_channels >= 16 and c.kernel_size == (3, 3) and
+                c.stride == (3, 3) and c.padding == (0, 0) and c.output_padding == (0, 0) and c.dilation == (1, 1) and
+                c.groups == 1 and x.shape[-1] * x.shape[-2] >= 512 and
+                os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
+            return "mfma_deconv"
         up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
         if x.shape[-1] * x.shape[-2] * up < 16384:
             return None
@@ -127,11 +134,17 @@ class Unit(nn.Module):
                     scale = torch.ones(co, device=c.weight.device)
                     shift = c.bias.float() if c.bias is not None else torch.zeros(co, device=c.weight.device)
                 w = c.weight.detach().float().contiguous()
-                wp = torch.empty(L.decnet_conv2d_mfma_packed_bytes(ci, co, k), dtype=torch.uint8, device=w.device)
-                with torch.cuda.device(w.device):
-                    _lib.check(L.decnet_conv2d_mfma_pack_weight(w.data_ptr(), wp.data_ptr(), ci, co, k,
-                                                                torch.cuda.current_stream(w.device).cuda_stream),
-                               "decnet_conv2d_mfma_pack_weight")
+                st = torch.cuda.current_stream(w.device).cuda_stream
+                if isinstance(c, nn.ConvTranspose2d):
+                    wp = torch.empty(L.decnet_deconv2d_mfma_packed_bytes(ci, co), dtype=torch.uint8, device=w.device)
+                    with torch.cuda.device(w.device):
+                        _lib.check(L.decnet_deconv2d_mfma_pack_weight(w.data_ptr(), wp.data_ptr(), ci, co, st),
+                                   "decnet_deconv2d_mfma_pack_weight")
+                else:
+                    wp = torch.empty(L.decnet_conv2d_mfma_packed_bytes(ci, co, k), dtype=torch.uint8, device=w.device)
+                    with torch.cuda.device(w.device):
+                        _lib.check(L.decnet_conv2d_mfma_pack_weight(w.data_ptr(), wp.data_ptr(), ci, co, k, st),
+                                   "decnet_conv2d_mfma_pack_weight")
                 self._mfold = (wp, scale.contiguous(), shift.contiguous())
             self._mfold_key = key
         return self._mfold
@@ -156,9 +169,26 @@ class Unit(nn.Module):
         _lib.check(rc, "decnet_conv2d_mfma_cat_bn_act")
         return y
 
+    def _forward_mfma_deconv(self, x):
+        from . import _lib
+        from .ops import _stream
+        wp, scale, shift = self._folded_mfma()
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        c = self.conv
+        y = torch.empty((B, c.out_channels, 3 * H, 3 * W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().decnet_deconv2d_mfma_k3s3_bn_act(x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                             y.data_ptr(), B, Cin, c.out_channels, H, W,
+                                                             1 if self.relu else 0, _stream(x))
+        _lib.check(rc, "decnet_deconv2d_mfma_k3s3_bn_act")
+        return y
+
     def _forward_hip(self, x, kind):
         if kind == "mfma":
             return self._forward_mfma(x)
+        if kind == "mfma_deconv":
+            return self._forward_mfma_deconv(x)
         from . import _lib
         from .ops import _stream
         w, scale, shift = self._folded()

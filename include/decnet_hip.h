@@ -240,6 +240,14 @@ int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int 
 int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int nseg, const void *w_packed,
                                   const float *scale, const float *shift, float *y, int B, int Cout, int H,
                                   int W, int k, int dilation, int relu, void *stream);
+/* Deconv2dUnit (ConvTranspose2d k = 3, stride 3, padding 0 + BN + ReLU, submodule.py:48-87; FeatureExtraction's
+ * deconv2 / deconv3 at 24 / 72 output channels) on the same kernels: every input pixel owns its 3 x 3 output block, so
+ * the layer is the 1 x 1 convolution to 9 Cout channels with a pixel-shuffle store.  w: torch [Cin,Cout,3,3];
+ * x [B,Cin,H,W] -> y [B,Cout,3H,3W]. */
+size_t decnet_deconv2d_mfma_packed_bytes(int Cin, int Cout);
+int decnet_deconv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, void *stream);
+int decnet_deconv2d_mfma_k3s3_bn_act(const float *x, const void *w_packed, const float *scale, const float *shift,
+                                     float *y, int B, int Cin, int Cout, int H, int W, int relu, void *stream);
 /* Refinement.get_warped_feats_by_homgrp (submodule.py:719-745): out[b,c,y,x] = bilinear(right[b,c];
  * (x - disp[b,y,x]) * W/(W-1) - 0.5, y * H/(H-1) - 0.5), zero padding.  right,out [B,C,H,W], disp [B,H,W]. */
 int decnet_warp_disparity(const float *right, const float *disp, float *out, int B, int C, int H, int W,

@@ -129,6 +129,23 @@ def test_deconv_unit_vs_torch_cpu(dev, cin, cout, relu, bn):
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,relu,bn,shape", [(72, 24, True, True, (2, 60, 108)), (216, 72, True, True, (2, 20, 36)),
+                                                     (16, 9, False, False, (1, 23, 31)), (40, 30, True, True, (1, 33, 50))])
+def test_mfma_deconv_unit_vs_torch_cpu(dev, cin, cout, relu, bn, shape):
+    """Deconv2dUnit with > 8 output channels: conv2d_mfma as a 1 x 1 convolution to 9 Cout channels + pixel shuffle."""
+    u = _unit(cin, cout, 3, relu=relu, bn=bn, transposed=True, seed=cin + cout)
+    B, H, W = shape
+    x = torch.randn(B, cin, H, W, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        ref = u.double()(x.double())
+        ud = u.float().to(dev)
+        xd = x.to(dev)
+        assert ud._hip_kind(xd) == "mfma_deconv"
+        got = ud(xd).cpu()
+    assert got.shape == ref.shape == (B, cout, 3 * H, 3 * W)
+    assert float((got.double() - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout", [(8, 24), (3, 8), (24, 20)])
 def test_stride3_conv_unit_vs_torch_cpu(dev, cin, cout):
     from decnet_amd.model import Unit

@@ -35,10 +35,6 @@ LAYERS = [
     ("refine1.conv2 24->24 d4", 8, (24,), 24, 180, 324, 3, 4),
     ("trans1 24->24 1x1", 16, (24,), 24, 180, 324, 1, 1),
     ("ctx 864->216 1x1", 16, (864,), 216, 20, 36, 1, 1),
-    ("deconv2 as 1x1 72->216", 16, (72,), 216, 60, 108, 1, 1),
-    ("deconv3 as 1x1 216->648", 16, (216,), 648, 20, 36, 1, 1),
-    ("conv2.0 s2d as 1x1 216->72", 16, (216,), 72, 60, 108, 1, 1),
-    ("conv3_1 s2d as 1x1 648->216", 16, (648,), 216, 20, 36, 1, 1),
 ]
 
 
