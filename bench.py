@@ -269,6 +269,28 @@ def pack_mask_bits(mask):
     return (z.view(B, H, wpr, 64) << sh).sum(-1).contiguous()
 
 
+def alt_gemm_leg():
+    """The hot-path step once more in a child process with the opt-in bf16x3 Winograd GEMM (the switch is read once per
+    process and changes the packed weights): value / ms_per_step / GEMM ms of that configuration."""
+    import subprocess
+    env = dict(os.environ, DECNET_WINO_GEMM="bf16x3")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "50", "--warmup", "8", "--no-cpu-baseline", "--no-train",
+           "--no-density-sweep", "--no-e2e", "--no-alt"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "wino_gemm_ms": d["roofline"]["ms"],
+                "fp32_equivalent_tflops": d["roofline"]["achieved"],
+                "bf16_pipe_frac": 6.0 * d["roofline"]["achieved"] / 2500.0,
+                "note": "DECNET_WINO_GEMM=bf16x3: every fp32 product of the Winograd GEMMs as six bf16 products on "
+                        "v_mfma_f32_16x16x32_bf16, fp32 accumulation; tests/conv_numerics.py: 4.7e-6 relative error on "
+                        "the regularised volume against 5.7e-6 for the fp32 MFMA path.  bf16_pipe_frac = executed bf16 "
+                        "FLOPs / 2.5 PFLOP/s"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def e2e_bench(B, dev, iters=5):
     """Whole network forward (random-init weights, demo.sh hyper-parameters, thold 0.5 so that the
     untrained mask generator produces mixed masks) on B synthetic 960x540 pairs padded to 972x540."""
@@ -546,6 +568,10 @@ def main():
     ap.add_argument("--no-train", action="store_true",
                     help="skip the extra 'train' object (config 5: SpaMat forward+backward, stages 1-3)")
     ap.add_argument("--e2e", action="store_true", help="(default at 1 GPU) see --no-e2e")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the 'alt_wino_gemm_bf16x3' object: the same hot-path step in a child process with "
+                         "DECNET_WINO_GEMM=bf16x3 (the Winograd GEMMs as bf16x3 products on the bf16 matrix cores, same "
+                         "accuracy; not the default, so that `roofline` prices plain fp32 MFMA arithmetic)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra 'e2e' object: the whole inference graph (decnet_amd.model: the 2-D "
                          "trunk around the hot path) timed on the same batch, eager and as a HIP-graph replay")
@@ -740,6 +766,9 @@ def main():
                 out["e2e"] = e2e_bench(B, dev)
             except Exception as e:                      # never lose the bench line to the extra leg
                 out["e2e"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if (world == 1 and not args.no_alt and args.config == 2 and args.mask_density >= 1.0 and
+                os.environ.get("DECNET_WINO_GEMM", "") == ""):
+            out["alt_wino_gemm_bf16x3"] = alt_gemm_leg()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -36,12 +36,15 @@ def test_bench_line_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "pairs/s" and c["sample"]
     cv = d["roofline_costvol"]
     assert cv["bound"] == "hbm" and cv["peak"] == 8000.0 and 0 < cv["frac"] < 1.2
+    alt = d["alt_wino_gemm_bf16x3"]                    # the opt-in bf16x3 Winograd GEMM, measured in a child process
+    assert "error" not in alt, alt
+    assert alt["value"] > 0 and alt["wino_gemm_ms"] > 0 and 0 < alt["bf16_pipe_frac"] < 1.0
 
 
 def test_bench_train_leg_full_size():
     """The config-5 share at full size (4 pairs of 972x540, stages 1-3, forward + backward through the C ABI and
     through SpaMatFunction) under a test assertion, not only inside the driver's bench run; and --config 5 itself."""
-    d = _run("--no-e2e", "--no-density-sweep", "--no-cpu-baseline")
+    d = _run("--no-e2e", "--no-density-sweep", "--no-cpu-baseline", "--no-alt")
     tr = d["train"]
     assert "error" not in tr, tr
     for row in tr["by_density"]:
