@@ -35,6 +35,12 @@ LAYERS = [
     ("refine1.conv2 24->24 d4", 8, (24,), 24, 180, 324, 3, 4),
     ("trans1 24->24 1x1", 16, (24,), 24, 180, 324, 1, 1),
     ("ctx 864->216 1x1", 16, (864,), 216, 20, 36, 1, 1),
+    ("detail0.conv_sub0 72->8", 8, (72,), 8, 60, 108, 3, 1),
+    ("softatt0.conv0 72+4x1->8", 8, (72, 1, 1, 1, 1), 8, 60, 108, 3, 1),
+    ("detail1.conv_sub0 24->8", 8, (24,), 8, 180, 324, 3, 1),
+    ("softatt1.conv0 24+4x1->8", 8, (24, 1, 1, 1, 1), 8, 180, 324, 3, 1),
+    ("refine0.conv6 36->1", 8, (36,), 1, 60, 108, 3, 1),
+    ("detail0.deconv0 216->8 as 1x1->72", 8, (216,), 72, 20, 36, 1, 1),
 ]
 
 
