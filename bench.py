@@ -102,6 +102,7 @@ class HotPath:
         from decnet_amd import dist as decnet_dist
         self.decnet, self.dist = decnet_amd, decnet_dist
         self.B, self.dev, self.world = B, dev, world
+        self.coll = world > 1 or decnet_dist.force_collective()     # the per-step all-gather runs (RCCL)
         self.feats, self.masks = make_inputs(B, dev, density, seed=1000 * (int(os.environ.get("RANK", 0)) + 1))
         self.reg = make_regularizer(STAGES[0][0], dev)
         self.stage0 = decnet_amd.Stage0(self.reg)
@@ -148,7 +149,7 @@ class HotPath:
                 (L, R), (rm, tm) = self.feats[s], self.masks[s]
                 if events is not None and s == 3:
                     events["s3_beg"].record()
-                par = self.k & 1 if self.world > 1 else 0
+                par = self.k & 1 if self.coll else 0
                 if s == 3 and self.pending[par] is not None:  # the gather that read this buffer set two steps ago
                     self.pending[par].wait()
                     self.pending[par] = None
@@ -164,8 +165,8 @@ class HotPath:
         else:
             pred0 = stage0()
             sparse_stages()
-        disp = self.outs3[self.k & 1 if self.world > 1 else 0][0]
-        if self.world > 1:       # one RCCL all-gather of the per-rank disparity maps, not waited for here
+        disp = self.outs3[self.k & 1 if self.coll else 0][0]
+        if self.coll:            # one RCCL all-gather of the per-rank disparity maps, not waited for here
             par = self.k & 1
             disp, self.pending[par] = self.dist.gather_disparity(disp, n_pairs=self.world * self.B,
                                                                  out=self.gbuf[par], async_op=True)
@@ -252,10 +253,37 @@ def cpu_baseline(seed=17, budget_s=12.0, max_pairs=16):
         a, b = one_pair()
         t_s0, t_sp, n = t_s0 + a, t_sp + b, n + 1
     total = t_s0 + t_sp
-    return {"value": n / total, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs 972x540 max_disp 216 one after another (after 1 warm-up pair), mask density 1.0: "
-                      "torch-CPU stage 0 %.2f s + C/OpenMP SpaMat+SpaVar stages 1-3 %.2f s per pair"
-                      % (n, t_s0 / n, t_sp / n)}
+    res = {"value": n / total, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": "%d pairs 972x540 max_disp 216 one after another (after 1 warm-up pair), mask density 1.0: "
+                     "torch-CPU stage 0 %.2f s + C/OpenMP SpaMat+SpaVar stages 1-3 %.2f s per pair"
+                     % (n, t_s0 / n, t_sp / n)}
+    # "also a 1-thread number".  One thread is ~100x slower, so the sample is bounded: stage 0 on one pair
+    # (whole), stages 1-2 whole, and stage 3 on every 6th row block (image rows are independent: 90 of 540 rows, x 6)
+    try:
+        oracle.set_num_threads(1)
+        torch.set_num_threads(1)
+        t0 = time.time()
+        with torch.no_grad():
+            o0.stage0_forward(feats[0][0], feats[0][1], params, STAGES[0][3])
+        t1s0 = time.time() - t0
+        t1sp = 0.0
+        for s in (1, 2, 3):
+            (L, R), (rm, tm) = feats[s], masks[s]
+            frac = 6 if s == 3 else 1
+            if frac > 1:
+                rows = L.shape[2] // frac
+                L, R, rm, tm = (t[..., :rows, :].contiguous() for t in (L, R, rm, tm))
+            t0 = time.time()
+            o, _, _ = oracle.spamat_forward(L, R, rm, tm, STAGES[s][3])
+            oracle.spavar_forward(L, R, rm, tm, o, STAGES[s][3])
+            t1sp += (time.time() - t0) * frac
+        res["one_thread"] = {"value": 1.0 / (t1s0 + t1sp), "unit": "pairs/s", "cores": 1,
+                             "sample": "1 pair: torch-CPU stage 0 %.1f s (whole) + C SpaMat+SpaVar stages 1-3 %.1f s "
+                                       "(stage 3 timed on 90 of its 540 independent rows, x 6)" % (t1s0, t1sp)}
+    finally:
+        oracle.set_num_threads(cores)
+        torch.set_num_threads(cores)
+    return res
 
 
 def pack_mask_bits(mask):
@@ -441,6 +469,7 @@ class TrainShare:
     def __init__(self, B, dev, density, world):
         from decnet_amd import dist as dd, ops
         self.ops, self.B, self.world = ops, B, world
+        self.coll = world > 1 or dd.force_collective()
         self.feats, self.masks = make_inputs(B, dev, density, seed=555 + 1000 * int(os.environ.get("RANK", 0)))
         self.buf = {}
         for s in (1, 2, 3):
@@ -462,10 +491,10 @@ class TrainShare:
         for k, s in enumerate((3, 2, 1)):             # backward runs fine-to-coarse
             (L, R), (rm, tm), b = self.feats[s], self.masks[s], self.buf[s]
             ops.spamat_backward(L, R, rm, tm, b["o"], b["ss"], b["mc"], b["go"], b["gl"], b["gr"], STAGES[s][3])
-            if self.world > 1:
+            if self.coll:
                 for i in ([0], [1], list(range(2, nb)))[k]:
                     self.grads.reduce_async(i)
-        if self.world > 1:
+        if self.coll:
             self.grads.wait()
 
     def drain(self):
@@ -475,7 +504,7 @@ class TrainShare:
 def timed_region(step, drain, warmup, steps, world, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
@@ -488,7 +517,7 @@ def timed_region(step, drain, warmup, steps, world, dev):
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if torch.distributed.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -501,7 +530,7 @@ def main_train(args, B, dev, world, rank):
     with torch.no_grad():
         elapsed = timed_region(ts.step, ts.drain, args.warmup, args.steps, world, dev)
         t_ar = None
-        if world > 1:                                    # the gradient all-reduce alone, not overlapped: a
+        if ts.coll:                                      # the gradient all-reduce alone, not overlapped: a
             def ar():                                    # collective, so EVERY rank runs it (outside the timed region)
                 for i in range(len(ts.grads)):
                     ts.grads.reduce_async(i)
@@ -540,8 +569,11 @@ def main_train(args, B, dev, world, rank):
                              "bytes_per_launch": nb, "fwd_ms": tf},
                 "allreduce_alone_ms": t_ar,
             }
+            if ts.coll:
+                out["collective"] = {"backend": torch.distributed.get_backend(), "world": world,
+                                     "forced_at_world_1": world == 1, "allreduce_4_buckets_alone_ms": t_ar}
             print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
@@ -572,6 +604,12 @@ def main():
                     help="skip the 'alt_wino_gemm_bf16x3' object: the same hot-path step in a child process with "
                          "DECNET_WINO_GEMM=bf16x3 (the Winograd GEMMs as bf16x3 products on the bf16 matrix cores, same "
                          "accuracy; not the default, so that `roofline` prices plain fp32 MFMA arithmetic)")
+    ap.add_argument("--no-valu-floor", action="store_true",
+                    help="skip the live VALU-floor microbenchmark (a child process; profiling runs)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise RCCL (backend nccl) and run the per-step collectives (all-gather of the disparity "
+                         "maps; config 5: the bucketed gradient all-reduce) even with ONE rank: the N > 1 code path on a "
+                         "one-GPU box.  Adds a 'collective' object with the collective's latency and an equality check")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra 'e2e' object: the whole inference graph (decnet_amd.model: the 2-D "
                          "trunk around the hot path) timed on the same batch, eager and as a HIP-graph replay")
@@ -591,8 +629,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if args.force_collective:
+        os.environ["DECNET_FORCE_COLLECTIVE"] = "1"
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:             # plain `python bench.py --force-collective`: a world of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group("nccl", device_id=dev)
         if torch.distributed.get_world_size() != args.gpus:
             raise SystemExit("RCCL sees %d ranks, --gpus %d" % (torch.distributed.get_world_size(), args.gpus))
@@ -605,7 +652,7 @@ def main():
     hp.overlap = not args.no_overlap
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -711,7 +758,7 @@ def main():
                                   "bytes_counted_for_achieved": used, "bit_masks": by_density[-1]["bit_masks"]}
             # the dense pass against the bound that applies to it: instruction issue (VALU + fp32 MFMA)
             valu = None
-            if args.mask_density >= 1.0:
+            if args.mask_density >= 1.0 and not args.no_valu_floor:
                 fp32_dense = os.environ.get("DECNET_SPAMAT_DENSE", "") == "fp32"
                 vf = valu_floor(B * H3 * ((W3 + 15) // 16), 30, 32 if fp32_dense else 8)
                 if vf:
@@ -751,6 +798,17 @@ def main():
                                          "of 8 TB/s (DESIGN.md section 4); the HBM-shaped regime is the sparse one "
                                          "in roofline_costvol_sparse"},
         }
+        if hp.coll:
+            # the step's collective alone (not overlapped), and that what it delivers is what was sent
+            with torch.no_grad():
+                src = hp.outs3[0][0]
+                t_ag = time_kernel(lambda: hp.dist.gather_disparity(src, n_pairs=world * B), 20, warm=3)
+                got = hp.dist.gather_disparity(src, n_pairs=world * B)
+                s_, e_ = hp.dist.shard_range(world * B, rank, world)
+                out["collective"] = {"backend": torch.distributed.get_backend(), "world": world,
+                                     "forced_at_world_1": world == 1, "all_gather_alone_ms": t_ag,
+                                     "bytes_per_rank": src.numel() * 4,
+                                     "own_shard_equals_sent": bool(torch.equal(got[s_:e_], src))}
         if valu:
             out["roofline_costvol_valu"] = valu
         if sparse:
@@ -764,6 +822,10 @@ def main():
         if world == 1 and not args.no_e2e:
             try:
                 out["e2e"] = e2e_bench(B, dev)
+                # the end-to-end forward of the whole graph on the same batch (the HIP-graph replay where
+                # the capture worked: same kernels, no launch gaps), beside `value` = the hot path alone
+                hg = out["e2e"].get("hip_graph", {})
+                out["value_end_to_end"] = max(out["e2e"]["value"], hg.get("value", 0.0))
             except Exception as e:                      # never lose the bench line to the extra leg
                 out["e2e"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if (world == 1 and not args.no_alt and args.config == 2 and args.mask_density >= 1.0 and
@@ -772,7 +834,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -78,7 +78,12 @@ _lib = None
 
 
 class DecnetHipError(RuntimeError):
-    pass
+    """``code``: the C ABI's return value (negative: argument error, DECNET_ERR_* of include/decnet_hip.h;
+    positive: hipError_t; None: raised by the Python side)."""
+    code = None
+
+
+UNSUPPORTED = -3          # DECNET_ERR_UNSUPPORTED: valid arguments the gfx950 kernels of that entry do not cover
 
 
 def lib():
@@ -104,8 +109,11 @@ def check(rc, what):
     if rc == 0:
         return
     if rc < 0:
-        raise DecnetHipError("%s: %s (code %d)" % (what, ERRORS.get(rc, "error"), rc))
-    raise DecnetHipError("%s: HIP launch failed, hipError_t=%d" % (what, rc))
+        e = DecnetHipError("%s: %s (code %d)" % (what, ERRORS.get(rc, "error"), rc))
+    else:
+        e = DecnetHipError("%s: HIP launch failed, hipError_t=%d" % (what, rc))
+    e.code = rc
+    raise e
 
 
 def version():

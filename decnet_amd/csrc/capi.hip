@@ -120,7 +120,10 @@ int decnet_spamatvar_forward_bits(const float *ref, const float *tar, const unsi
     const void *p[] = {ref, tar, ref_bits, tar_bits, output, variance, sum_similarities, max_cost};
     int rc = decnet_check_spamat_args(p, 8, B, C, H, W, max_disp);
     if (rc) return rc;
-    // the matrix-core kernels only (the row-tile fallback reads float planes): band of <= 18 tiles, i.e. max_disp <= 272
+    // the matrix-core kernels only (the row-tile fallback reads float planes): band of <= 18 tiles, i.e. max_disp <= 272;
+    // DECNET_SPAMAT_KERNEL=rowtile pins a kernel this entry does not have -> UNSUPPORTED, the caller falls back to the
+    // float-mask entry (decnet_amd.model does)
+    if (spamat_pinned() == 1) return DECNET_ERR_UNSUPPORTED;
     return decnet_mfma_forward(2, ref, tar, reinterpret_cast<const float *>(ref_bits),
                                reinterpret_cast<const float *>(tar_bits), nullptr, output, variance,
                                sum_similarities, max_cost, B, C, H, W, max_disp, spamat_pinned() != 3, 1,

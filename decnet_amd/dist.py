@@ -8,8 +8,17 @@ batch, weights are replicated once at start-up, and the single collective per st
 all-gather of the per-rank disparity maps (7.5 MB per rank for the KITTI config: latency-bound,
 far below the xGMI link budget, so no bucketing or ring tuning is needed).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def force_collective():
+    """DECNET_FORCE_COLLECTIVE=1 (bench.py / eval --force-collective): run the collectives even in a world of one
+    rank, so that the RCCL branch (init_process_group("nccl"), all_gather_into_tensor, the bucketed all_reduce)
+    really executes on a single-GPU box; results are the same as without it."""
+    return os.environ.get("DECNET_FORCE_COLLECTIVE", "0") == "1"
 
 
 def shard_range(n_pairs, rank, world):
@@ -44,7 +53,7 @@ def gather_disparity(local, n_pairs=None, group=None, out=None, async_op=False):
     ``async_op=True`` (RCCL, even shards): returns ``(gathered, work)`` without making the current
     stream wait -- the collective then overlaps the next batch's kernels; call ``work.wait()``
     before reading ``gathered`` or reusing ``local`` / ``out``."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective()):
         return (local, None) if async_op else local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -111,7 +120,7 @@ class GradBuckets:
     def reduce_async(self, i):
         if i in self.pending:
             raise RuntimeError("bucket %d is already being reduced" % i)
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not force_collective()):
             self.pending[i] = None
             return
         self.pending[i] = dist.all_reduce(self.bucket(i), op=dist.ReduceOp.SUM, group=self.group, async_op=True)

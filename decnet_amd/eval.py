@@ -15,6 +15,7 @@ processes (one per GPU, RCCL); rank r evaluates the contiguous shard ``decnet_am
 batches with weights resident, and the per-batch metrics are gathered once at the end.
 """
 import argparse
+import math
 import os
 import sys
 import time
@@ -68,6 +69,9 @@ def build_parser():
     p.add_argument("--resume", default=None)
     p.add_argument("--save2where", default="./Log/FirstTry")
     p.add_argument("--gpus", type=int, default=1, help="processes (one per GPU); > 1 without a launcher starts them")
+    p.add_argument("--force-collective", action="store_true",
+                   help="initialise RCCL and gather the metrics through it even with one rank (the N > 1 path on a "
+                        "one-GPU box; same result)")
     return p
 
 
@@ -123,8 +127,16 @@ def test(args, model=None):
     torch.manual_seed(17)                                               # eval.py:106
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    coll = world > 1 or getattr(args, "force_collective", False)
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                             # --force-collective without a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group("nccl", device_id=device)
     kind = get_loader(args.dataset)
     kw = dict(use_detail=bool(args.use_detail), max_disp=192)
@@ -141,8 +153,13 @@ def test(args, model=None):
         (left, right, disparity, _image, lm1, lm2, lm3, rm1, rm2, rm3, ori_h, ori_w, names, n_disp) = collate(
             [dataset[i] for i in batches[bi]])
         with torch.no_grad():
-            if args.dataset.lower() in ("middleburymask", "pairs"):     # eval.py:173-174
-                model.max_disp = int(n_disp[0])
+            # eval.py:173-174 sets model.max_disp = n_disp for Middlebury.  Only a sample that carries a real range
+            # overrides --max_disp (a pair directory without calib.txt and the .npy layout report n_disp <= 0), and the
+            # range is rounded up to the next multiple of 27 as demo.py:149-155 does, so that the per-stage ranges are
+            # max_disp / 27, / 9, / 3 exactly (the constructor's own assertion, SparseDenseNetRefinementMask.py:42)
+            nd = max(int(v) for v in n_disp)
+            model.max_disp = int(math.ceil(nd / 27.0) * 27) if nd > 0 else int(args.max_disp)
+            assert model.max_disp % 27 == 0, "max_disp must be a multiple of 27 (down_scale^(num_stage-1))"
             left, right, disparity = left.to(device), right.to(device), disparity.to(device)
             lms, rms = [m.to(device) for m in (lm1, lm2, lm3)], [m.to(device) for m in (rm1, rm2, rm3)]
             torch.cuda.synchronize()
@@ -161,17 +178,24 @@ def test(args, model=None):
                                 disparity_to_uint16(pred[j:j + 1], int(ori_h[j]), int(ori_w[j])))
                 print("[{}/{}]   submission cost time: {}".format(bi, len(batches), dt))
     result = None
-    if world > 1:
-        allrec = [None] * world
-        torch.distributed.all_gather_object(allrec, rec)
-        rec = sorted(r for part in allrec for r in part)
+    if coll:
+        # the per-batch metrics of every rank, once, as one all-gather of a fixed-size tensor over RCCL
+        nb = len(batches)
+        mine = torch.full((nb, 2), float("nan"), device=device, dtype=torch.float64)
+        for bi, epe, l3 in rec:
+            mine[bi, 0], mine[bi, 1] = epe, l3
+        allm = torch.empty((world, nb, 2), device=device, dtype=torch.float64)
+        torch.distributed.all_gather_into_tensor(allm, mine)
+        merged = torch.where(torch.isnan(allm), torch.zeros_like(allm), allm).sum(0).cpu()
+        have = (~torch.isnan(allm[..., 0])).any(0).cpu()
+        rec = [(bi, float(merged[bi, 0]), float(merged[bi, 1])) for bi in range(nb) if bool(have[bi])]
     if args.is_eval and rec:
         result = (float(np.mean([r[1] for r in rec])), float(np.mean([r[2] for r in rec])))
         if rank == 0:
             print("epe: {}, loss_3: {}".format(result[0], result[1]))
     if rank == 0:
         print("The testing is completed: {}".format(time.strftime("%Y-%m-%d %H:%M:%S", time.localtime(time.time()))))
-    if world > 1:
+    if coll:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return result

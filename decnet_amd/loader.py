@@ -1,6 +1,6 @@
 """Evaluation-time data sources for decnet_amd.eval.
 
-Two layouts, both yielding the tuple the reference's datasets return in test mode
+Three layouts, all yielding the tuple the reference's datasets return in test mode
 (loader/SceneflowMask.py:198-203): ``left, right, disparity, image, left_mask1..3, right_mask1..3,
 ori_h, ori_w, name, n_disp`` with the images padded on the top/left to multiples of 27
 (SceneflowMask.py:118-130), scaled to [0,1] and normalised with the ImageNet statistics (:152-153,
@@ -9,6 +9,9 @@ ori_h, ori_w, name, n_disp`` with the images padded on the top/left to multiples
 * ``NpyPairs``  -- the reference's pre-baked format: ``<root>/<split>/*.npy`` arrays ``[H,W,7]`` (left RGB,
   right RGB, disparity; SceneflowMask.py:115,144-146) and, optionally, the pickled list of six detail masks
   next to them in ``<root>/<split>_mask/<name>`` (left fine->coarse, right fine->coarse; :166-185).
+* ``MiddleburyPickles`` -- loader/MiddleburyMask.py:117-131: ``<root>/<MiddEval3?_processed>/<split dir>/*.pkl``, each a
+  pickled dict ``{ndisp, im0, im1 [, disparity] [, disparity_right]}`` (inf in the ground truth -> 0), masks pickled in
+  ``<split dir>_mask/<name>`` as above; the sample's own ``ndisp`` travels as ``n_disp`` (eval.py:173-174).
 * ``PairDirectory`` -- demo.py's layout: ``<root>/<name>/im0.png, im1.png [, calib.txt] [, disp0.pfm |
   disp0.png (uint16, x256)]``.
 
@@ -112,7 +115,49 @@ class NpyPairs(_Base):
             with open(mpath, "rb") as f:
                 m = pickle.load(f)
             lm, rm = m[0:3], m[3:6]
-        return self._item(arr[..., 0:3], arr[..., 3:6], arr[..., 6], name, self.n_disp, lm, rm)
+        # no per-sample disparity range in this layout: n_disp <= 0 tells eval to keep --max_disp
+        return self._item(arr[..., 0:3], arr[..., 3:6], arr[..., 6], name, -1, lm, rm)
+
+
+class MiddleburyPickles(_Base):
+    """loader/MiddleburyMask.py:13-131 in test / eval mode (no augmentation)."""
+    _SPLITS = {"train_Q": ("MiddEval3Q_processed", "trainingQ"), "eval_Q": ("MiddEval3Q_processed", "trainingQ"),
+               "train_H": ("MiddEval3H_processed", "trainingH"), "eval_H": ("MiddEval3H_processed", "trainingH"),
+               "train_F": ("MiddEval3F_processed", "trainingF"), "train_AG": ("", "MiddZip_raw_split_dense"),
+               "train_allF": ("", "MiddZip_processed"), "eval_allF": ("", "MiddZip_processed"),
+               "train_allF_EL": ("", "MiddZip_processed_EL"), "eval_allF_EL": ("", "MiddZip_processed_EL"),
+               "train_merge": ("", "MiddMerged"), "test_Q": ("MiddEval3Q_processed", "testQ"),
+               "test_H": ("MiddEval3H_processed", "testH"), "test_F": ("MiddEval3F_processed", "testF")}
+
+    def __init__(self, root, split="eval_H", **kw):
+        super().__init__(**kw)
+        if split not in self._SPLITS:
+            raise Exception("Nu such split: {}".format(split))               # MiddleburyMask.py:78
+        sub, self.split = self._SPLITS[split]
+        self.datapath = os.path.join(root, sub) if sub else root
+        d = os.path.join(self.datapath, self.split)
+        self.files = sorted(os.listdir(d)) if os.path.isdir(d) else []
+        if not self.files:
+            raise Exception("No files for ld=[%s] found in %s" % (self.split, self.datapath))
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        with open(os.path.join(self.datapath, self.split, self.files[i]), "rb") as f:
+            raw = pickle.load(f)
+        left, right = np.asarray(raw["im0"]), np.asarray(raw["im1"])
+        disp = raw.get("disparity")
+        disp = np.zeros(left.shape[:2], np.float32) if disp is None else np.array(disp, dtype=np.float32)
+        disp[~np.isfinite(disp)] = 0                                       # MiddleburyMask.py:128
+        name = self.files[i].split(".pkl")[0]
+        lm = rm = None
+        mpath = os.path.join(self.datapath, self.split + "_mask", name)
+        if os.path.exists(mpath):
+            with open(mpath, "rb") as f:
+                m = pickle.load(f)
+            lm, rm = m[0:3], m[3:6]
+        return self._item(left, right, disp, self.files[i].split(".")[0], int(raw["ndisp"]), lm, rm)
 
 
 class PairDirectory(_Base):
@@ -139,10 +184,11 @@ class PairDirectory(_Base):
         else:
             disp = np.zeros(left.shape[:2], np.float32)
         n = read_ndisp(os.path.join(d, "calib.txt"))
-        return self._item(left, right, disp, self.names[i], n if n > 0 else self.n_disp)
+        return self._item(left, right, disp, self.names[i], n)            # n <= 0: no calib.txt, eval keeps --max_disp
 
 
 def get_loader(name):
-    """loader/__init__.py:8-21 (the four reference datasets share the pre-baked .npy layout) + 'pairs'."""
+    """loader/__init__.py:8-21: KITTI15 / Sceneflow / DrivingStereo share the pre-baked .npy layout, Middlebury has its
+    pickled-dict layout; + 'pairs' (demo.py's directories)."""
     return {"kitti15mask": NpyPairs, "sceneflowmask": NpyPairs, "drivingstereomask": NpyPairs,
-            "middleburymask": NpyPairs, "pairs": PairDirectory}[name.lower()]
+            "middleburymask": MiddleburyPickles, "pairs": PairDirectory}[name.lower()]

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._lib import DecnetHipError, UNSUPPORTED
 from .ops import spamatvar_forward, spamatvar_forward_bits
 from .stage0 import CostRegNetNoDown, Stage0
 
@@ -54,7 +55,7 @@ class Unit(nn.Module):
             return None
         c = self.conv
         # many channels: the bf16x3 matrix-core kernel (csrc/conv2d_mfma.hip) where the image gives it enough
-        # workgroups (>= 60 x 108; below that the library's kernels win)
+        # workgroups (>= 4096 pixels, e.g. the 60 x 108 level; at 20 x 36 the library's kernels win)
         if (isinstance(c, nn.Conv2d) and c.out_channels >= 24 and c.in_channels >= 16 and c.kernel_size in ((1, 1), (3, 3)) and
                 c.stride == (1, 1) and c.dilation[0] == c.dilation[1] and c.groups == 1 and c.padding_mode == "zeros" and
                 c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and x.shape[-1] * x.shape[-2] >= 4096 and
@@ -249,7 +250,11 @@ class Unit(nn.Module):
     def forward(self, x):
         kind = self._hip_kind(x)
         if kind is not None:
-            return self._forward_hip(x, kind)
+            try:
+                return self._forward_hip(x, kind)
+            except DecnetHipError as e:                 # e.g. LDS budget / grid limits of the matrix-core kernel
+                if e.code != UNSUPPORTED:
+                    raise
         if isinstance(x, (tuple, list)):
             x = torch.cat(tuple(x), 1)
         if (self.bn is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda and
@@ -663,9 +668,16 @@ class SparseDenseNetRefinementMask(nn.Module):
             dense = self.dynamic_upsampling[stage - 1](pred, L)           # reference :178
             # SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch; the masks as the bit-packed
             # copies the mask kernel wrote where there are any (the float planes stay what SoftAttention reads)
+            res = None
             if (lbits is not None and rbits is not None and cur_max_disp <= 272 and
                     os.environ.get("DECNET_SPAMAT_BITS", "1") == "1"):
-                sparse, var, _, _ = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, cur_max_disp)
+                try:
+                    res = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, cur_max_disp)
+                except DecnetHipError as e:             # shapes only the float-mask entry's fallback kernels cover
+                    if e.code != UNSUPPORTED:
+                        raise
+            if res is not None:
+                sparse, var, _, _ = res
             else:
                 sparse, var, _, _ = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(),
                                                       rmask.contiguous(), cur_max_disp)

@@ -362,6 +362,11 @@ class CostRegNetNoDown(nn.Module):
         if P[0]["Ci"] != C:
             raise ValueError("feature maps have %d channels, module expects %d"
                              % (left_feature_map.shape[1], int(self.units()[0].conv.weight.shape[1])))
+        if any(not p["relu"] for p in P[:7]):
+            # decnet_stage0_forward applies ReLU behind each of the seven C -> C units, as the reference's network
+            # does (submodule.py:624-648); a unit built with relu=False needs the per-layer path (forward())
+            raise _lib.DecnetHipError("decnet_stage0_forward: a Conv3dUnit without ReLU is not covered by the "
+                                      "single-entry stage-0 path; use CostRegNetNoDown.forward")
         L = _lib.lib()
         dev = left.device
         variant = WINO_VARIANT.get(algo, 3)

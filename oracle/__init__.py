@@ -25,8 +25,10 @@ _F = ctypes.POINTER(ctypes.c_float)
 
 def build(force=False):
     """Compile liboracle.so / liboracle_nofma.so with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "spamat_oracle.c")
     need = force or not all(
-        os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle.so", "liboracle_nofma.so"))
+        os.path.exists(os.path.join(_HERE, n)) and os.path.getmtime(os.path.join(_HERE, n)) >= os.path.getmtime(src)
+        for n in ("liboracle.so", "liboracle_nofma.so"))
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
@@ -59,6 +61,12 @@ def _p(a):
 
 def num_threads():
     return int(_lib().oracle_num_threads())
+
+
+def set_num_threads(n):
+    """OpenMP threads of the C restatement (bench.py's one-thread cpu_baseline figure)."""
+    for fma in (True, False):
+        _lib(fma).oracle_set_num_threads(int(n))
 
 
 def spamat_forward(ref, tar, rmask, tmask, max_disp, fma=True):

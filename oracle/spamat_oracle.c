@@ -352,3 +352,12 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+/* bench.py's one-thread cpu_baseline leg */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}

@@ -34,6 +34,7 @@ def test_bench_line_contract():
     assert 0.3 < r["frac"] < 1.0 and "wino_gemm" in r["kernel"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "pairs/s" and c["sample"]
+    assert c["one_thread"]["cores"] == 1 and 0 < c["one_thread"]["value"] <= c["value"] * 1.5
     cv = d["roofline_costvol"]
     assert cv["bound"] == "hbm" and cv["peak"] == 8000.0 and 0 < cv["frac"] < 1.2
     alt = d["alt_wino_gemm_bf16x3"]                    # the opt-in bf16x3 Winograd GEMM, measured in a child process
@@ -57,7 +58,86 @@ def test_bench_train_leg_full_size():
     assert d5["roofline"]["bound"] == "hbm" and 0 < d5["roofline"]["frac"] < 1.0 and d5["config"]["grad_buckets"] == 4
 
 
-def test_bench_other_configs_run():
-    for cfg in ("3", "4"):
-        d = _run("--config", cfg, "--no-e2e", "--no-train", "--no-density-sweep", "--no-cpu-baseline")
-        assert d["value"] > 0 and ("config %s" % cfg) in d["config"]["workload"]
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_bench_other_configs_run_and_match_the_oracle_at_full_size(cfg):
+    """Configs 3 (KITTI 1242x378, 4 pairs per GPU) and 4 (Middlebury half-res 1512x1026, max_disp 270): the bench
+    line, and -- on the bench's own full-size tensors -- sampled rows of every SpaMat/SpaVar stage against the
+    oracle (rows are independent, so a row sample at full width is the full-size kernel's result) plus the
+    stage-0 result of one pair against the torch-CPU oracle."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import decnet_amd
+    import oracle
+    from oracle import stage0 as o0
+    d = _run("--config", str(cfg), "--no-e2e", "--no-train", "--no-density-sweep", "--no-cpu-baseline")
+    assert d["value"] > 0 and ("config %s" % cfg) in d["config"]["workload"]
+    bench.set_config(cfg)
+    try:
+        dev = torch.device("cuda:0")
+        B = bench.DEFAULT_B
+        for dens in (1.0, 0.4):
+            feats, masks = bench.make_inputs(B, dev, dens, seed=77)
+            for s in (1, 2, 3):
+                C, H, W, D = bench.STAGES[s]
+                (L, R), (rm, tm) = feats[s], masks[s]
+                o, v, ss, mc = decnet_amd.spamatvar_forward(L, R, rm, tm, D)
+                for b, y in ((0, 0), (B - 1, H - 1), (B // 2, H // 3)):
+                    sl = (slice(b, b + 1), slice(None), slice(y, y + 1))
+                    Lc, Rc = L[sl].cpu(), R[sl].cpu()
+                    rmc, tmc = rm[b:b + 1, y:y + 1].cpu(), tm[b:b + 1, y:y + 1].cpu()
+                    oo, so, mo = oracle.spamat_forward(Lc, Rc, rmc, tmc, D)
+                    vo, _, _ = oracle.spavar_forward(Lc, Rc, rmc, tmc, oo, D)
+                    assert np.abs(o[b, y].cpu().numpy() - oo[0, 0]).max() < 2e-4, (cfg, s, dens, b, y)
+                    assert np.allclose(mc[b, y].cpu().numpy(), mo[0, 0], rtol=1e-5, atol=1e-6)
+                    assert np.allclose(ss[b, y].cpu().numpy(), so[0, 0], rtol=2e-5, atol=1e-6)
+                    assert np.allclose(v[b, y].cpu().numpy(), vo[0, 0], rtol=2e-4, atol=2e-3)
+        # stage 0 of one pair at the config's full stage-0 shape
+        C0, H0, W0, D0 = bench.STAGES[0]
+        params = o0.random_params(C0, 5)
+        reg = decnet_amd.CostRegNetNoDown(C0, 2 * C0, "cor")
+        for u, p in zip(reg.units(), params):
+            u.conv.weight.data = p["w"].clone()
+            u.bn.weight.data, u.bn.bias.data = p["bn"][0].clone(), p["bn"][1].clone()
+            u.bn.running_mean.data, u.bn.running_var.data = p["bn"][2].clone(), p["bn"][3].clone()
+        reg = reg.to(dev).eval()
+        g = torch.Generator().manual_seed(5)
+        left = torch.relu(torch.randn(1, C0, H0, W0, generator=g))
+        right = torch.relu(torch.randn(1, C0, H0, W0, generator=g))
+        with torch.no_grad():
+            pred = decnet_amd.Stage0(reg)(left.to(dev), right.to(dev), D0)
+            pred_o, _, _ = o0.stage0_forward(left, right, params, D0)
+        assert float((pred.cpu() - pred_o).abs().max()) < 1e-3, cfg
+    finally:
+        bench.set_config(2)
+
+
+def test_bench_collectives_run_through_rccl_in_a_world_of_one():
+    """The N > 1 branch on the one GPU there is: under torch.distributed.run --nproc-per-node 1 with
+    --force-collective bench.py initialises RCCL (backend nccl), barriers through it, runs the per-step
+    all_gather_into_tensor(async_op=True) + work.wait() (config 2) and the 4-bucket async gradient all-reduce
+    (config 5); the gathered shard must equal what was sent and the value must be that of a normal run's order."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5",
+            "--warmup", "2", "--force-collective", "--no-e2e", "--no-train", "--no-density-sweep", "--no-cpu-baseline",
+            "--no-alt"]
+    for extra in ([], ["--config", "5"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+        c = d["collective"]
+        print("collective:", c)
+        assert c["backend"] == "nccl" and c["world"] == 1 and c["forced_at_world_1"] is True and d["value"] > 0
+        if extra:
+            assert c["allreduce_4_buckets_alone_ms"] > 0
+        else:
+            assert c["own_shard_equals_sent"] is True and c["all_gather_alone_ms"] > 0
+    # plain `python bench.py --force-collective` (no launcher): a world of one by itself
+    d = _run("--force-collective", "--no-e2e", "--no-train", "--no-density-sweep", "--no-cpu-baseline", "--no-alt")
+    assert d["collective"]["backend"] == "nccl" and d["collective"]["own_shard_equals_sent"] is True

@@ -46,7 +46,7 @@ def test_npy_pairs_layout(tmp_path):
     ds = loader.get_loader("SceneflowMask")(str(root), split="test", use_detail=True)
     assert len(ds) == 1
     left, right, disp, image, lm1, lm2, lm3, rm1, rm2, rm3, oh, ow, name, nd = ds[0]
-    assert left.shape == (3, 54, 54) and disp.shape == (54, 54) and (oh, ow, name, nd) == (30, 50, "a", 192)
+    assert left.shape == (3, 54, 54) and disp.shape == (54, 54) and (oh, ow, name, nd) == (30, 50, "a", -1)   # no per-sample range
     assert lm1.shape == (6, 6) and lm3.shape == (54, 54) and float(lm1.sum()) == 0      # coarsest first
     assert float(disp[:24].abs().sum()) == 0 and float(disp[:, :4].abs().sum()) == 0   # top/left padding
     np.testing.assert_allclose(disp[24:, 4:].numpy(), arr[..., 6])
@@ -69,13 +69,41 @@ def test_pair_directory_and_batches(tmp_path):
     ds = loader.get_loader("pairs")(str(tmp_path), use_detail=False)
     assert len(ds) == 2
     s0, s1 = ds[0], ds[1]
-    assert s0[-1] == 192 and s1[-1] == 54 and s0[-2] == "p0"
+    assert s0[-1] <= 0 and s1[-1] == 54 and s0[-2] == "p0"          # no calib.txt: eval keeps --max_disp
     assert s0[4].shape == (3, 6) and s0[6].shape == (27, 54) and set(np.unique(s0[6].numpy())) <= {0.0, 1.0}
     assert float(s0[2].max()) < 30.001 and float(s0[2].max()) > 1
     b = dev_eval.batches_of(ds, 8)
     assert b == [[0, 1]]
     cols = dev_eval.collate([s0, s1])
     assert cols[0].shape == (2, 3, 27, 54) and cols[12] == ["p0", "p1"]
+
+
+def test_middlebury_pickle_layout(tmp_path):
+    """loader/MiddleburyMask.py:117-131: pickled dicts {ndisp, im0, im1, disparity} under
+    <root>/MiddEval3H_processed/trainingH, masks under trainingH_mask; the sample's ndisp travels as n_disp."""
+    rng = np.random.RandomState(2)
+    d = tmp_path / "MiddEval3H_processed" / "trainingH"
+    d.mkdir(parents=True)
+    (tmp_path / "MiddEval3H_processed" / "trainingH_mask").mkdir()
+    gt = rng.rand(20, 31).astype(np.float32) * 50
+    gt[3, 4] = np.inf
+    with open(d / "Adirondack.pkl", "wb") as f:
+        pickle.dump({"ndisp": 145, "im0": rng.randint(0, 255, (20, 31, 3)).astype(np.uint8),
+                     "im1": rng.randint(0, 255, (20, 31, 3)).astype(np.uint8), "disparity": gt.copy()}, f)
+    masks = [np.ones((27, 54)), np.ones((9, 18)), np.zeros((3, 6))] * 2
+    with open(tmp_path / "MiddEval3H_processed" / "trainingH_mask" / "Adirondack", "wb") as f:
+        pickle.dump(masks, f)
+    ds = loader.get_loader("MiddleburyMask")(str(tmp_path), split="eval_H", use_detail=True)
+    left, right, disp, image, lm1, lm2, lm3, rm1, rm2, rm3, oh, ow, name, nd = ds[0]
+    assert (oh, ow, name, nd) == (20, 31, "Adirondack", 145) and left.shape == (3, 27, 54)
+    assert float(disp[7 + 3, 23 + 4]) == 0 and np.isfinite(disp.numpy()).all()      # inf -> 0 (MiddleburyMask.py:128)
+    np.testing.assert_allclose(disp[7:, 23:].numpy()[5], gt[5])
+    assert lm1.shape == (3, 6) and lm3.shape == (27, 54)
+    try:
+        loader.get_loader("MiddleburyMask")(str(tmp_path), split="nope")
+        assert False
+    except Exception as e:
+        assert "split" in str(e)
 
 
 def test_parser_defaults_follow_eval_sh():

@@ -12,7 +12,11 @@ import sys
 from collections import defaultdict
 
 KEYS = {                                    # substring of the kernel name -> key in traffic.json
-    "wino_gemm": "wino_gemm",
+    # exact template names: "wino_gemm" alone would also match wino_gemm_persist / wino_gemm_bf16x3.  The step's
+    # GEMM is the first of these that ran (the default is the persistent kernel at Ci = 216)
+    "wino_gemm_persist<": "wino_gemm",
+    "wino_gemm_bf16x3": "wino_gemm",
+    "wino_gemm<": "wino_gemm",
     "wino_input_transform": "wino_input_transform",
     "wino_output_transform": "wino_output_transform",
     "conv3d_k3_igemm": "conv3d_k3_igemm",
@@ -60,12 +64,17 @@ def main():
                    "L2<->fabric requests: Infinity-Cache hits are included, so for kernels whose working set "
                    "stays in the 256 MiB Infinity Cache this is an upper bound on HBM bytes."}
     for sub, key in KEYS.items():
-        f = [v[0] for k, v in fetch.items() if sub in k]
-        w = [v[0] for k, v in write.items() if sub in k]
+        if key in res:
+            continue
+        # launch-weighted mean over every kernel name that matches (template instantiations of one kernel)
+        f = [v for k, v in fetch.items() if sub in k]
+        w = [v for k, v in write.items() if sub in k]
         if not f or not w:
             continue
-        fb, wb = 2.0 * 1024.0 * f[0], 1024.0 * w[0]
-        res[key] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb}
+        fm = sum(a * n for a, n in f) / sum(n for _, n in f)
+        wm = sum(a * n for a, n in w) / sum(n for _, n in w)
+        fb, wb = 2.0 * 1024.0 * fm, 1024.0 * wm
+        res[key] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "kernel_match": sub}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
         if k != "_how":
