@@ -47,6 +47,9 @@ N_PARAMS = 13_190_000        # parameters of the shipped base_channels=8 network
 CONFIG_NAME, PAD_H, PAD_W, MAX_DISP, DEFAULT_B = CONFIGS[2]
 
 
+_JSON_OUT = None       # the process's real stdout when a process group is up (see main)
+
+
 def stage_shapes(h, w, md):
     """(C, H, W, D) for stage 0..3 of the shipped 4-stage / scale-3 network."""
     return [(216, h // 27, w // 27, md // 27), (72, h // 9, w // 9, md // 9), (24, h // 3, w // 3, md // 3),
@@ -572,7 +575,7 @@ def main_train(args, B, dev, world, rank):
             if ts.coll:
                 out["collective"] = {"backend": torch.distributed.get_backend(), "world": world,
                                      "forced_at_world_1": world == 1, "allreduce_4_buckets_alone_ms": t_ar}
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -632,6 +635,12 @@ def main():
     if args.force_collective:
         os.environ["DECNET_FORCE_COLLECTIVE"] = "1"
     if world > 1 or args.force_collective:
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON
+        # line (everything else this process or its libraries print goes to stderr)
+        global _JSON_OUT
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:             # plain `python bench.py --force-collective`: a world of one
             import socket
@@ -833,7 +842,7 @@ def main():
             out["alt_wino_gemm_bf16x3"] = alt_gemm_leg()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -89,7 +89,8 @@ def test_bench_other_configs_run_and_match_the_oracle_at_full_size(cfg):
                     rmc, tmc = rm[b:b + 1, y:y + 1].cpu(), tm[b:b + 1, y:y + 1].cpu()
                     oo, so, mo = oracle.spamat_forward(Lc, Rc, rmc, tmc, D)
                     vo, _, _ = oracle.spavar_forward(Lc, Rc, rmc, tmc, oo, D)
-                    assert np.abs(o[b, y].cpu().numpy() - oo[0, 0]).max() < 2e-4, (cfg, s, dens, b, y)
+                    # fp32 expectation over D candidates: 2e-4 px at D = 216, ~1e-6 D beyond
+                    assert np.abs(o[b, y].cpu().numpy() - oo[0, 0]).max() < max(2e-4, 1.3e-6 * D), (cfg, s, dens, b, y)
                     assert np.allclose(mc[b, y].cpu().numpy(), mo[0, 0], rtol=1e-5, atol=1e-6)
                     assert np.allclose(ss[b, y].cpu().numpy(), so[0, 0], rtol=2e-5, atol=1e-6)
                     assert np.allclose(v[b, y].cpu().numpy(), vo[0, 0], rtol=2e-4, atol=2e-3)
