@@ -27,9 +27,6 @@
 // off_{j+1} + d_{j+1} + 1), one barrier per row step.
 #include "common.h"
 #include <stdio.h>
-#ifndef DECNET_CHAIN_VARIANT
-#define DECNET_CHAIN_VARIANT 0
-#endif
 
 typedef float f32x4_h __attribute__((ext_vector_type(4)));
 typedef int i32x4_h __attribute__((ext_vector_type(4)));
@@ -80,19 +77,14 @@ __device__ __forceinline__ void split3(float x, int &h, int &m, int &l) {
 __device__ __forceinline__ int pack2(int hi_elem, int lo_elem) {       // (elem j+1, elem j) -> one dword of bf16 pairs
     return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302);
 }
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int ring_slot(int r, int nr) { return (int)((unsigned)(r + 64 * nr) % (unsigned)nr); }
 
 // The plan is read straight from the kernel-argument segment (constant address space: scalar loads, dynamic indexing
 // without a private copy of the 2.7 KB structure)
-#if DECNET_CHAIN_VARIANT & 4
-typedef const PlanK CPlan;
-typedef const LayerK CLayer;
-typedef const PartK CPart;
-#else
 typedef const __attribute__((address_space(4))) PlanK CPlan;
 typedef const __attribute__((address_space(4))) LayerK CLayer;
 typedef const __attribute__((address_space(4))) PartK CPart;
-#endif
 
 // A tiles: w [Cout][Cin][KT] (Conv2d weight), sign[Cin] (+-1 or null) -> wp[(tap * G + c) * 64 + lane]
 __global__ void chain2d_pack(const float *__restrict__ w, const float *__restrict__ sign, i32x4_h *__restrict__ wp,
@@ -191,22 +183,18 @@ __device__ __forceinline__ void compute_rows(CPlan &P, CLayer &Lj, const i32x4_h
     const int wpr64 = P.wpr * 64, wpr4 = P.wpr * 4, dbg = P.debug;
     // everything loaded so far is complete from here on: the compiler's waitcnt bookkeeping must not make the first
     // MFMA of every row step wait on the vector-memory counter
-#if !(DECNET_CHAIN_VARIANT & 1)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-#if !(DECNET_CHAIN_VARIANT & 2)
     if (!SLOW) {
 #pragma unroll
         for (int st = 0; st < 9 * GG; ++st) asm volatile("" : "+v"(a[st]));
     }
     asm volatile("" : "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1));
-#endif
 
     for (int s = s_first; s < R; ++s) {
         const int r = s + off, gy = y0 + r;
         const bool act = r >= -halo && r < R + halo;
         const bool row_in = gy >= 0 && gy < H;
-        if (act && !(LAST && !row_in)) {
+        if (act && !(LAST && !row_in) && !(dbg & 128)) {
             int rowoff[3];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ring_slot(r + (ky - 1) * dil, nr_in) * pitch * 16;
@@ -214,9 +202,10 @@ __device__ __forceinline__ void compute_rows(CPlan &P, CLayer &Lj, const i32x4_h
             const int out_row = lane_out + ring_slot(r, nr_out) * pitch * 16;
             const float *abuf = reinterpret_cast<const float *>(lds + lds_aux) + (s & 1) * naux * pitch;
             const bool rows_ok = r >= 0 && r < R;
-            for (int t = tw0; t < ntiles; t += nw) {
+            // two tiles per pass: their MFMA chains and epilogues are independent, so the scheduler interleaves them
+            // (one wave per SIMD slot issues a dependent instruction only every ~8 cycles)
+            auto tile_acc = [&](int t, f32x4_h &acc0, f32x4_h &acc1) {
                 const int col0 = c0 + 16 * t;
-                f32x4_h acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 if (row_in && !(dbg & 1)) {
                     if (!SLOW) {
                         tile_mfma<GG, 9>(a, lds, lane_in, rowoff, col0, dil, gstride, acc0, acc1);
@@ -236,6 +225,9 @@ __device__ __forceinline__ void compute_rows(CPlan &P, CLayer &Lj, const i32x4_h
                         }
                     }
                 }
+            };
+            auto tile_epi = [&](int t, const f32x4_h &acc0, const f32x4_h &acc1) {
+                const int col0 = c0 + 16 * t;
                 // ---- epilogue: lane (n, q) holds output channels 2 q, 2 q + 1 of pixel col0 + n ----
                 const int col = col0 + n, gx = xorg + col;
                 const bool in = row_in && gx >= 0 && gx < W;
@@ -255,16 +247,6 @@ __device__ __forceinline__ void compute_rows(CPlan &P, CLayer &Lj, const i32x4_h
                     if (2 * q + 1 >= cout) v1 = 0.f;
                 }
                 if (!in) { v0 = 0.f; v1 = 0.f; }
-                if (dbg & 1024) {          // diagnostic: channels 0 / 1 of this lane's B operand at the centre tap
-                    const int dw = *reinterpret_cast<const int *>(lds + lane_in + rowoff[KT == 9 ? 1 : 0] + col0 * 16);
-                    v0 = __int_as_float(dw << 16);
-                    v1 = __int_as_float(dw & 0xffff0000);
-                }
-                if (dbg & 2048) {          // diagnostic: element 0 / 1 of this lane's A operand of the centre tap
-                    const int dw = SLOW ? 0 : a[4 * GG][0];
-                    v0 = __int_as_float(dw << 16);
-                    v1 = __int_as_float(dw & 0xffff0000);
-                }
                 if (!LAST) {
                     if (col < pitch && !(dbg & 16)) {
                         int h0, m0, l0, h1, m1, l1;
@@ -314,6 +296,15 @@ __device__ __forceinline__ void compute_rows(CPlan &P, CLayer &Lj, const i32x4_h
                             bits16[((size_t)b * H + gy) * wpr4 + (xt >> 4)] = (unsigned short)(bal & 0xffffull);
                     }
                 }
+            };
+            constexpr bool PAIR = GG == 1 && !SLOW;                // (18+ weight tiles leave no room for a second set)
+            for (int t = tw0; t < ntiles; t += (PAIR ? 2 : 1) * nw) {
+                f32x4_h p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f}, q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+                const bool two = PAIR && t + nw < ntiles;           // wave-uniform
+                tile_acc(t, p0, p1);
+                if (two) tile_acc(t + nw, q0, q1);
+                tile_epi(t, p0, p1);
+                if (two) tile_epi(t + nw, q0, q1);
             }
         }
         __syncthreads();
@@ -321,39 +312,245 @@ __device__ __forceinline__ void compute_rows(CPlan &P, CLayer &Lj, const i32x4_h
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Loader waves (NLW of the NWAVES): everything that touches HBM on the input side.  They run one row AHEAD with two
-// register sets: in step s they issue the loads of row s + 1 + off0 and then split + store row s + off0 (issued one step
-// earlier) into the level-0 ring -- so only these waves ever wait for memory, and only for loads that had a whole row
-// step to arrive.  The compute waves never execute a vector-memory load inside the loop (stores are fire and forget):
-// in-order vmcnt would otherwise make every MFMA block wait for the row loads issued in front of it.
+// Loader waves (NLW of the 8): everything that touches HBM on the input side.  They run one row AHEAD with two register
+// sets: in step s they issue the loads of row s + 1 + off0 and then split + store row s + off0 (issued one step earlier)
+// into the level-0 ring -- so only these waves ever wait for memory, and only for loads that had a whole row step to
+// arrive.  The compute waves never execute a vector-memory load inside the loop (stores are fire and forget): in-order
+// vmcnt would otherwise make every MFMA block wait for the row loads issued in front of it.
+// One instantiation per (source kind, units per lane): the row loop must stay small -- the 64 KB instruction cache is
+// shared by the loader and the compute loops of two CUs, and a loop body that spans every source kind x 4 units x 2
+// register sets measured 2.3 us per row step with NO loads in it (instruction fetch), against 0.25 us for the barrier.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int SRC, int KU>
+__device__ __forceinline__ void loader_rows(CPlan &P, unsigned char *lds, int lt, int b, int xs, int y0) {
+    const int H = P.H, W = P.W, pitch = P.pitch, R = P.R, H0 = P.H0, Wrow = P.Wrow, Wpad = P.Wpad, G0 = P.G0, nr0 = P.nr0;
+    const size_t HW = (size_t)H * W;
+    const int xorg = xs - H0;
+    const int off0 = P.L[0].off + P.L[0].dil + 1, s_first = -H0 - off0;
+    const int naux = P.naux, aoff = naux ? P.L[P.aux_layer].off : 0;
+    const int nunits = P.ustart[G0];
+    const float **ptab = reinterpret_cast<const float **>(lds + P.lds_tab);
+    const int tstr = G0 * nr0 * pitch * 16;              // bytes between the terms of level 0
+    int u_p[KU], u_sub[KU], u_kind[KU], u_dst[KU], u_c8[KU];
+    unsigned u_ok[KU];                                   // bit e: channel e exists
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+        const int u = lt + NLW * 64 * k;
+        u_p[k] = 0; u_sub[k] = 0; u_kind[k] = -1; u_dst[k] = 0; u_ok[k] = 0; u_c8[k] = 0;
+        int c = 0;
+        if (u < nunits) {
+            for (int cc = 1; cc < G0; ++cc)
+                if (u >= P.ustart[cc]) c = cc;
+            const int v = u - P.ustart[c];
+            u_sub[k] = v / Wpad;
+            u_p[k] = v - u_sub[k] * Wpad;
+            u_kind[k] = DECNET_PART_PLAIN;
+            if (SRC != DECNET_PART_PLAIN) {
+#pragma unroll
+                for (int g = 0; g < MAXG0; ++g)
+                    if (g < G0 && c == g) u_kind[k] = P.gkind[g];
+            }
+            u_dst[k] = P.lds0 + (c * nr0 * pitch + u_p[k]) * 16;
+        }
+        u_c8[k] = 8 * c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (ptab[8 * c + e] != nullptr) u_ok[k] |= 1u << e;
+        if (u_kind[k] != DECNET_PART_PLAIN) u_ok[k] = 0;
+    }
+    int a_ch[MAXKA], a_p[MAXKA];
+#pragma unroll
+    for (int k = 0; k < MAXKA; ++k) {
+        const int v = lt + NLW * 64 * k;
+        a_ch[k] = -1; a_p[k] = 0;
+        if (v < naux * Wpad) {
+            a_ch[k] = v / Wpad;
+            a_p[k] = v - a_ch[k] * Wpad;
+        }
+    }
+    float rawA[KU][8], rawB[KU][8], axA[MAXKA], axB[MAXKA];
+    const int dbg = P.debug;
 
-template <int MAXG, int SINK>
-__global__ __launch_bounds__(THREADS, 1) void chain2d(PlanK P_by_value, const i32x4_h *__restrict__ wp) {
-#if DECNET_CHAIN_VARIANT & 4
-    CPlan &P = P_by_value;
-#else
+    auto issue = [&](float (&raw)[KU][8], float (&ax)[MAXKA], int s) {
+        const int r0 = s + off0, gy0 = y0 + r0;
+        const bool row_in = r0 >= -H0 && r0 < R + H0 && gy0 >= 0 && gy0 < H;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            if (SRC != DECNET_PART_PLAIN && u_kind[k] != DECNET_PART_PLAIN) continue;     // wave-uniform
+            const int gx = xorg + u_p[k];
+            const bool in = row_in && gx >= 0 && gx < W && u_p[k] < Wrow;
+            const int o = in ? gy0 * W + gx : 0;
+            // a missing channel (tail of the last group) loads channel 0 of its group instead and is zeroed afterwards: the
+            // loads of a row are unconditional (the plane pointers come from the table in LDS: no registers held)
+            const float *cp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cp[e] = ptab[u_c8[k] + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                raw[k][e] = (u_ok[k] && !(dbg & 2)) ? as_global(cp[e] != nullptr ? cp[e] : cp[0])[o] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (!in || !((u_ok[k] >> e) & 1)) raw[k][e] = 0.f;
+        }
+        if (naux) {
+            // auxiliary planes of the consuming layer's row one step ahead
+            const int ra = s + 1 + aoff, gya = y0 + ra;
+            const bool arow = gya >= 0 && gya < H;
+#pragma unroll
+            for (int k = 0; k < MAXKA; ++k) {
+                float v = 0.f;
+                if (a_ch[k] >= 0) {
+                    const int gx = xorg + a_p[k];
+                    if (arow && gx >= 0 && gx < W && a_p[k] < Wrow)
+                        v = as_global(P.auxp[a_ch[k]])[(size_t)b * P.auxbs[a_ch[k]] + (size_t)gya * W + gx];
+                }
+                ax[k] = v;
+            }
+        }
+    };
+
+    auto commit = [&](float (&raw)[KU][8], float (&ax)[MAXKA], int s) {
+        const int r0 = s + off0, gy0 = y0 + r0;
+        const bool src_active = r0 >= -H0 && r0 < R + H0;
+        const bool src_row_in = gy0 >= 0 && gy0 < H;
+        if (src_active && !(dbg & 4)) {
+            const int slot0 = ring_slot(r0, nr0) * pitch * 16;
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int kind = u_kind[k];
+                if (kind < 0 || u_p[k] >= pitch) continue;
+                const int p = u_p[k], gx = xorg + p;
+                unsigned char *dst = lds + u_dst[k] + slot0;
+                const bool in = src_row_in && gx >= 0 && gx < W && p < Wrow;
+                if (SRC != DECNET_PART_DECONV || kind != DECNET_PART_DECONV) {
+                    float v[8];
+                    if (SRC != DECNET_PART_WARP || kind == DECNET_PART_PLAIN) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = raw[k][e];
+                    } else {
+#pragma clang fp contract(off)
+                        // Refinement.get_warped_feats_by_homgrp (submodule.py:719-745), the arithmetic of
+                        // csrc/conv2d_small.hip:warp_disparity
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                        if (in) {
+                            CPart &pt = P.wrp;
+                            const float d = as_global(pt.aux)[(size_t)b * HW + (size_t)gy0 * W + gx];
+                            const float cx = ((float)gx - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
+                            const float cy = (float)gy0 / ((float)(H - 1.0) / 2.0f) - 1.0f;
+                            const float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
+                            const float fx = floorf(ix), fy = floorf(iy);
+                            const int x0 = (int)fx, yy0 = (int)fy, x1 = x0 + 1, yy1 = yy0 + 1;
+                            const float nw = (fx + 1.0f - ix) * (fy + 1.0f - iy), ne = (ix - fx) * (fy + 1.0f - iy);
+                            const float sw = (fx + 1.0f - ix) * (iy - fy), se = (ix - fx) * (iy - fy);
+                            const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+                            const bool vy0 = (unsigned)yy0 < (unsigned)H, vy1 = (unsigned)yy1 < (unsigned)H;
+                            gfp rb = as_global(pt.p) + (size_t)b * pt.c * HW;
+                            // clamped taps: every load is issued, invalid ones are dropped by the selects below
+                            const int xa = vx0 ? x0 : 0, xb = vx1 ? x1 : 0, ya = vy0 ? yy0 : 0, yb = vy1 ? yy1 : 0;
+                            const int o00 = ya * W + xa, o01 = ya * W + xb, o10 = yb * W + xa, o11 = yb * W + xb;
+                            float t00[8], t01[8], t10[8], t11[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                gfp rp = rb + (size_t)(e < pt.c ? e : 0) * HW;
+                                t00[e] = rp[o00]; t01[e] = rp[o01]; t10[e] = rp[o10]; t11[e] = rp[o11];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float t = 0.f;
+                                if (vy0 && vx0) t += t00[e] * nw;
+                                if (vy0 && vx1) t += t01[e] * ne;
+                                if (vy1 && vx0) t += t10[e] * sw;
+                                if (vy1 && vx1) t += t11[e] * se;
+                                v[e] = e < pt.c ? t : 0.f;
+                            }
+                        }
+                    }
+                    int hh[8], mm[8], ll[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) split3(v[e], hh[e], mm[e], ll[e]);
+                    i32x4_h th, tm, tl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        th[e] = pack2(hh[2 * e + 1], hh[2 * e]);
+                        tm[e] = pack2(mm[2 * e + 1], mm[2 * e]);
+                        tl[e] = pack2(ll[2 * e + 1], ll[2 * e]);
+                    }
+                    *reinterpret_cast<i32x4_h *>(dst) = th;
+                    *reinterpret_cast<i32x4_h *>(dst + tstr) = tm;
+                    *reinterpret_cast<i32x4_h *>(dst + 2 * tstr) = tl;
+                } else {
+                    // DECNET_PART_DECONV: ConvTranspose2d k = 3, stride 3 of the coarser level (Deconv2dUnit, submodule.py:
+                    // 48-87): out[co][y][x] = act(scale * sum_ci pre[ci][y/3][x/3] w[ci][co][y%3][x%3] + shift); this unit =
+                    // output channels 4 sub .. 4 sub + 3 of one pixel (the fmaf chain of csrc/conv2d_small.hip:deconv2d_k3s3)
+                    CPart &pt = P.dec;
+                    const int sub = u_sub[k];
+                    float o4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (in) {
+                        const int Y = gy0 / 3, X = gx / 3, ky = gy0 - 3 * Y, kx = gx - 3 * X;
+                        const int Hc = H / 3, Wc = W / 3;
+                        gfp pp = as_global(pt.p) + (size_t)b * pt.cp * Hc * Wc + (size_t)Y * Wc + X;
+                        gfp wq = as_global(pt.aux) + (ky * 3 + kx) * 8 + 4 * sub;
+                        for (int ci = 0; ci < pt.cp; ++ci) {
+                            const float xv = pp[(size_t)ci * Hc * Wc];
+                            const float w0 = wq[ci * 72], w1 = wq[ci * 72 + 1], w2 = wq[ci * 72 + 2], w3 = wq[ci * 72 + 3];
+                            o4[0] = fmaf(xv, w0, o4[0]); o4[1] = fmaf(xv, w1, o4[1]);
+                            o4[2] = fmaf(xv, w2, o4[2]); o4[3] = fmaf(xv, w3, o4[3]);
+                        }
+                        gfp scp = as_global(pt.sc) + 4 * sub, shp = as_global(pt.sh) + 4 * sub;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o4[e] = fmaf(o4[e], scp[e], shp[e]);
+                            if (pt.relu) o4[e] = fmaxf(o4[e], 0.f);
+                        }
+                    }
+                    int hh[4], mm[4], ll[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split3(o4[e], hh[e], mm[e], ll[e]);
+                    *reinterpret_cast<i32x2_h *>(dst + 8 * sub) = i32x2_h{pack2(hh[1], hh[0]), pack2(hh[3], hh[2])};
+                    *reinterpret_cast<i32x2_h *>(dst + tstr + 8 * sub) = i32x2_h{pack2(mm[1], mm[0]), pack2(mm[3], mm[2])};
+                    *reinterpret_cast<i32x2_h *>(dst + 2 * tstr + 8 * sub) = i32x2_h{pack2(ll[1], ll[0]), pack2(ll[3], ll[2])};
+                }
+            }
+        }
+        if (naux) {
+            // aux row s + 1 + aoff -> buffer (s + 1) & 1
+            float *abuf = reinterpret_cast<float *>(lds + P.lds_aux) + ((s + 1) & 1) * naux * pitch;
+#pragma unroll
+            for (int k = 0; k < MAXKA; ++k)
+                if (a_ch[k] >= 0 && a_p[k] < pitch) abuf[a_ch[k] * pitch + a_p[k]] = ax[k];
+        }
+    };
+
+    if (dbg & 64) {                                      // timing experiment: barriers only
+        for (int s = s_first; s < R; ++s) __syncthreads();
+        return;
+    }
+    issue(rawA, axA, s_first);
+    for (int s = s_first; s < R; s += 2) {
+        issue(rawB, axB, s + 1);
+        commit(rawA, axA, s);
+        __syncthreads();
+        if (s + 1 < R) {
+            issue(rawA, axA, s + 2);
+            commit(rawB, axB, s + 1);
+            __syncthreads();
+        }
+    }
+}
+
+template <int SINK, int SRC, int OCC>
+__global__ __launch_bounds__(THREADS, 2 * OCC) void chain2d(PlanK P_by_value, const i32x4_h *__restrict__ wp) {
     CPlan &P = *(CPlan *)__builtin_amdgcn_kernarg_segment_ptr();      // = P_by_value, at offset 0
-#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    if ((P_by_value.debug & 512) && tid == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0)
-        printf("AS4 vs by-value: TW %d %d R %d %d pitch %d %d L0.G %d %d L0.woff %d %d L0.c0 %d %d nr0 %d %d lds_tab %d %d out %p %p sc0 %f %f\n", P.TW,
-               P_by_value.TW, P.R, P_by_value.R, P.pitch, P_by_value.pitch, P.L[0].G, P_by_value.L[0].G, P.L[0].woff,
-               P_by_value.L[0].woff, P.L[0].c0, P_by_value.L[0].c0, P.nr0, P_by_value.nr0, P.lds_tab, P_by_value.lds_tab,
-               (void *)P.out, (void *)P_by_value.out, P.L[0].sc[1], P_by_value.L[0].sc[1]);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, xs = blockIdx.x * P.TW, y0 = blockIdx.y * P.R;
-    const int xorg = xs - P.H0;                         // global x of LDS column 0
-    const int H = P.H, W = P.W, pitch = P.pitch;
-    const size_t HW = (size_t)H * W;
-    const int off0 = P.L[0].off + P.L[0].dil + 1;       // row skew of the source: off_0 = off_1 + d_1 + 1
-    const int s_first = -P.H0 - off0;
-    const int aoff = P.naux ? P.L[P.aux_layer].off : 0;
+    const size_t HW = (size_t)P.H * P.W;
 
     // plane 0 of every PLAIN channel for this workgroup's sample (or null), as a table in LDS
     const float **ptab = reinterpret_cast<const float **>(lds + P.lds_tab);
-    if (tid < P.G0 * 8) {
+    if (tid < MAXG0 * 8) {
         const float *c1 = P.chp[tid], *c2 = P.chp2[tid];         // (loads first, then selects of the loaded values)
         const int cc = P.chc[tid];
         const bool second = b >= P.bsplit && c2 != nullptr;
@@ -375,206 +572,11 @@ __global__ __launch_bounds__(THREADS, 1) void chain2d(PlanK P_by_value, const i3
     __syncthreads();
 
     if (wave >= NCW) {
-        // =============================================== loader waves ===============================================
         const int lt = tid - NCW * 64;                   // 0 .. NLW * 64 - 1
-        const int nunits = P.ustart[P.G0];
-        int u_c[MAXKU], u_p[MAXKU], u_sub[MAXKU], u_kind[MAXKU];
-#pragma unroll
-        for (int k = 0; k < MAXKU; ++k) {
-            const int u = lt + NLW * 64 * k;
-            u_c[k] = 0; u_p[k] = 0; u_sub[k] = 0; u_kind[k] = -1;
-            if (u < nunits) {
-                int c = 0;
-                for (int cc = 1; cc < P.G0; ++cc)
-                    if (u >= P.ustart[cc]) c = cc;
-                const int v = u - P.ustart[c];
-                u_c[k] = c;                              // (with generated parts Wpad is a multiple of 64: one kind per wave)
-                u_sub[k] = v / P.Wpad;
-                u_p[k] = v - u_sub[k] * P.Wpad;
-#pragma unroll
-                for (int g = 0; g < MAXG0; ++g)
-                    if (g < P.G0 && c == g) u_kind[k] = P.gkind[g];
-            }
-        }
-        int a_ch[MAXKA], a_p[MAXKA];
-#pragma unroll
-        for (int k = 0; k < MAXKA; ++k) {
-            const int v = lt + NLW * 64 * k;
-            a_ch[k] = -1; a_p[k] = 0;
-            if (v < P.naux * P.Wpad) {
-                a_ch[k] = v / P.Wpad;
-                a_p[k] = v - a_ch[k] * P.Wpad;
-            }
-        }
-        float rawA[MAXKU][8], rawB[MAXKU][8], axA[MAXKA], axB[MAXKA];
-
-        auto issue = [&](float (&raw)[MAXKU][8], float (&ax)[MAXKA], int s) {
-            const int r0 = s + off0, gy0 = y0 + r0;
-            const bool row_in = r0 >= -P.H0 && r0 < P.R + P.H0 && gy0 >= 0 && gy0 < H;
-#pragma unroll
-            for (int k = 0; k < MAXKU; ++k) {
-                if (u_kind[k] != DECNET_PART_PLAIN) continue;                       // wave-uniform
-                const int gx = xorg + u_p[k];
-                const bool in = row_in && gx >= 0 && gx < W && u_p[k] < P.Wrow;
-                const int o = in ? gy0 * W + gx : 0;
-                const float *cp[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) cp[e] = ptab[8 * u_c[k] + e];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = 0.f;
-                    if (in && cp[e] != nullptr && !(P.debug & 2)) v = as_global(cp[e])[o];
-                    if (P.debug & 4096) v = (float)((uintptr_t)cp[e] & 0xffffff);      // diagnostics
-                    if (P.debug & 8192) v = (float)o;
-                    if (P.debug & 16384) v = (float)(8 * u_c[k] + e) + 0.125f * k;
-                    raw[k][e] = v;
-                }
-            }
-            // auxiliary planes of the consuming layer's row one step ahead
-            const int ra = s + 1 + aoff, gya = y0 + ra;
-            const bool arow = gya >= 0 && gya < H;
-#pragma unroll
-            for (int k = 0; k < MAXKA; ++k) {
-                float v = 0.f;
-                if (a_ch[k] >= 0) {
-                    const int gx = xorg + a_p[k];
-                    if (arow && gx >= 0 && gx < W && a_p[k] < P.Wrow)
-                        v = as_global(P.auxp[a_ch[k]])[(size_t)b * P.auxbs[a_ch[k]] + (size_t)gya * W + gx];
-                }
-                ax[k] = v;
-            }
-        };
-
-        auto commit = [&](float (&raw)[MAXKU][8], float (&ax)[MAXKA], int s) {
-#if DECNET_CHAIN_VARIANT & 8
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            const int r0 = s + off0, gy0 = y0 + r0;
-            const bool src_active = r0 >= -P.H0 && r0 < P.R + P.H0;
-            const bool src_row_in = gy0 >= 0 && gy0 < H;
-            if (src_active && !(P.debug & 4)) {
-                const int slot0 = ring_slot(r0, P.nr0);
-                const int tstr = P.G0 * P.nr0 * pitch * 16;
-#pragma unroll
-                for (int k = 0; k < MAXKU; ++k) {
-                    const int kind = u_kind[k];
-                    if (kind < 0 || u_p[k] >= pitch) continue;
-                    const int c = u_c[k], p = u_p[k], gx = xorg + p;
-                    unsigned char *dst = lds + P.lds0 + ((c * P.nr0 + slot0) * pitch + p) * 16;
-                    const bool in = src_row_in && gx >= 0 && gx < W && p < P.Wrow;
-                    if (kind == DECNET_PART_PLAIN || kind == DECNET_PART_WARP) {
-                        float v[8];
-                        if (kind == DECNET_PART_PLAIN) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = raw[k][e];
-                            if (P.debug & 32768) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] = (float)(gy0 * 8 + e);
-                            }
-                        } else {
-#pragma clang fp contract(off)
-                            // Refinement.get_warped_feats_by_homgrp (submodule.py:719-745), the arithmetic of
-                            // csrc/conv2d_small.hip:warp_disparity
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-                            if (in) {
-                                CPart &pt = P.wrp;
-                                const float d = as_global(pt.aux)[(size_t)b * HW + (size_t)gy0 * W + gx];
-                                const float cx = ((float)gx - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
-                                const float cy = (float)gy0 / ((float)(H - 1.0) / 2.0f) - 1.0f;
-                                const float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
-                                const float fx = floorf(ix), fy = floorf(iy);
-                                const int x0 = (int)fx, yy0 = (int)fy, x1 = x0 + 1, yy1 = yy0 + 1;
-                                const float nw = (fx + 1.0f - ix) * (fy + 1.0f - iy), ne = (ix - fx) * (fy + 1.0f - iy);
-                                const float sw = (fx + 1.0f - ix) * (iy - fy), se = (ix - fx) * (iy - fy);
-                                const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
-                                const bool vy0 = (unsigned)yy0 < (unsigned)H, vy1 = (unsigned)yy1 < (unsigned)H;
-                                gfp rb = as_global(pt.p) + (size_t)b * pt.c * HW;
-                                float t00[8], t01[8], t10[8], t11[8];
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {                      // all 32 taps in flight
-                                    const bool ce = e < pt.c;
-                                    gfp rp = rb + (size_t)e * HW;
-                                    t00[e] = ce && vy0 && vx0 ? rp[(size_t)yy0 * W + x0] : 0.f;
-                                    t01[e] = ce && vy0 && vx1 ? rp[(size_t)yy0 * W + x1] : 0.f;
-                                    t10[e] = ce && vy1 && vx0 ? rp[(size_t)yy1 * W + x0] : 0.f;
-                                    t11[e] = ce && vy1 && vx1 ? rp[(size_t)yy1 * W + x1] : 0.f;
-                                }
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    float t = 0.f;
-                                    if (vy0 && vx0) t += t00[e] * nw;
-                                    if (vy0 && vx1) t += t01[e] * ne;
-                                    if (vy1 && vx0) t += t10[e] * sw;
-                                    if (vy1 && vx1) t += t11[e] * se;
-                                    v[e] = t;
-                                }
-                            }
-                        }
-                        int hh[8], mm[8], ll[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) split3(v[e], hh[e], mm[e], ll[e]);
-                        i32x4_h th, tm, tl;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            th[e] = pack2(hh[2 * e + 1], hh[2 * e]);
-                            tm[e] = pack2(mm[2 * e + 1], mm[2 * e]);
-                            tl[e] = pack2(ll[2 * e + 1], ll[2 * e]);
-                        }
-                        *reinterpret_cast<i32x4_h *>(dst) = th;
-                        *reinterpret_cast<i32x4_h *>(dst + tstr) = tm;
-                        *reinterpret_cast<i32x4_h *>(dst + 2 * tstr) = tl;
-                    } else {
-                        // DECNET_PART_DECONV: ConvTranspose2d k = 3, stride 3 of the coarser level (Deconv2dUnit, submodule.py:
-                        // 48-87): out[co][y][x] = act(scale * sum_ci pre[ci][y/3][x/3] w[ci][co][y%3][x%3] + shift); this unit =
-                        // output channels 4 sub .. 4 sub + 3 of one pixel (the fmaf chain of csrc/conv2d_small.hip:deconv2d_k3s3)
-                        CPart &pt = P.dec;
-                        const int sub = u_sub[k];
-                        float o4[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (in) {
-                            const int Y = gy0 / 3, X = gx / 3, ky = gy0 - 3 * Y, kx = gx - 3 * X;
-                            const int Hc = H / 3, Wc = W / 3;
-                            gfp pp = as_global(pt.p) + (size_t)b * pt.cp * Hc * Wc + (size_t)Y * Wc + X;
-                            gfp wq = as_global(pt.aux) + (ky * 3 + kx) * 8 + 4 * sub;
-                            for (int ci = 0; ci < pt.cp; ++ci) {
-                                const float xv = pp[(size_t)ci * Hc * Wc];
-                                const float w0 = wq[ci * 72], w1 = wq[ci * 72 + 1], w2 = wq[ci * 72 + 2], w3 = wq[ci * 72 + 3];
-                                o4[0] = fmaf(xv, w0, o4[0]); o4[1] = fmaf(xv, w1, o4[1]);
-                                o4[2] = fmaf(xv, w2, o4[2]); o4[3] = fmaf(xv, w3, o4[3]);
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                o4[e] = fmaf(o4[e], pt.sc[4 * sub + e], pt.sh[4 * sub + e]);
-                                if (pt.relu) o4[e] = fmaxf(o4[e], 0.f);
-                            }
-                        }
-                        int hh[4], mm[4], ll[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) split3(o4[e], hh[e], mm[e], ll[e]);
-                        *reinterpret_cast<i32x2_h *>(dst + 8 * sub) = i32x2_h{pack2(hh[1], hh[0]), pack2(hh[3], hh[2])};
-                        *reinterpret_cast<i32x2_h *>(dst + tstr + 8 * sub) = i32x2_h{pack2(mm[1], mm[0]), pack2(mm[3], mm[2])};
-                        *reinterpret_cast<i32x2_h *>(dst + 2 * tstr + 8 * sub) = i32x2_h{pack2(ll[1], ll[0]), pack2(ll[3], ll[2])};
-                    }
-                }
-            }
-            // aux row s + 1 + aoff -> buffer (s + 1) & 1
-            float *abuf = reinterpret_cast<float *>(lds + P.lds_aux) + ((s + 1) & 1) * P.naux * pitch;
-#pragma unroll
-            for (int k = 0; k < MAXKA; ++k)
-                if (a_ch[k] >= 0 && a_p[k] < pitch) abuf[a_ch[k] * pitch + a_p[k]] = ax[k];
-        };
-
-        issue(rawA, axA, s_first);
-        for (int s = s_first; s < P.R; s += 2) {
-            issue(rawB, axB, s + 1);
-            commit(rawA, axA, s);
-            __syncthreads();
-            if (s + 1 < P.R) {
-                issue(rawA, axA, s + 2);
-                commit(rawB, axB, s + 1);
-                __syncthreads();
-            }
-        }
+        const int ku = ceil_div_dev(P.ustart[P.G0], NLW * 64);
+        if (ku <= 1) loader_rows<SRC, 1>(P, lds, lt, b, xs, y0);
+        else if (OCC == 2 || ku == 2) loader_rows<SRC, 2>(P, lds, lt, b, xs, y0);
+        else loader_rows<SRC, 4>(P, lds, lt, b, xs, y0);
         return;
     }
 
@@ -590,12 +592,12 @@ __global__ __launch_bounds__(THREADS, 1) void chain2d(PlanK P_by_value, const i3
     if (P.L[j].KT == 9 && G == 1) {
         if (last) compute_rows<1, true, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
         else compute_rows<1, false, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
-    } else if (MAXG >= 2 && P.L[j].KT == 9 && G == 2) {
-        if (last) compute_rows<MAXG >= 2 ? 2 : 1, true, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
-        else compute_rows<MAXG >= 2 ? 2 : 1, false, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
-    } else if (MAXG >= 3 && P.L[j].KT == 9 && G == 3) {
-        if (last) compute_rows<MAXG >= 3 ? 3 : 1, true, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
-        else compute_rows<MAXG >= 3 ? 3 : 1, false, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
+    } else if (P.L[j].KT == 9 && G == 2) {
+        if (last) compute_rows<2, true, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
+        else compute_rows<2, false, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
+    } else if (OCC == 1 && P.L[j].KT == 9 && G == 3) {
+        if (last) compute_rows<OCC == 1 ? 3 : 1, true, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
+        else compute_rows<OCC == 1 ? 3 : 1, false, SINK, false>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
     } else {
         if (last) compute_rows<1, true, SINK, true>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
         else compute_rows<1, false, SINK, true>(P, P.L[j], wp, lds, wave, lane, b, xs, y0, j);
@@ -655,7 +657,7 @@ int decnet_chain2d_forward(const decnet_chain_desc *d, void *stream) {
             P.gkind[g0] = s.kind;
             P.gpart[g0] = i;
             if (s.kind == DECNET_PART_DECONV) { P.dec = k; ++ndec; } else { P.wrp = k; ++nwrp; }
-            if (ndec > 1 || nwrp > 1) return DECNET_ERR_UNSUPPORTED;
+            if (ndec > 1 || nwrp > 1 || (ndec && nwrp)) return DECNET_ERR_UNSUPPORTED;
             ch += 8;                                   // a generated part owns its whole group
         } else {
             ch += s.c;
@@ -728,15 +730,22 @@ int decnet_chain2d_forward(const decnet_chain_desc *d, void *stream) {
     // ---- strip width: the cheapest candidate that fits LDS and the loader lanes' units per row ----
     const int upg_total = [&] { int u = 0; for (int g = 0; g < G0; ++g) u += P.gkind[g] == DECNET_PART_DECONV ? 2 : 1; return u; }();
     double best = 1e300;
-    int bestTW = 0;
+    int bestTW = 0, occ = 1;
+    // two workgroups per CU (16 waves, <= 128 registers) unless a layer needs 27 weight tiles in registers
+    int want_occ = 2;
+    for (int l = 0; l < NL; ++l)
+        if (P.L[l].KT == 9 && P.L[l].G == 3) want_occ = 1;
+    if (d->debug & 32) want_occ = 1;
+    const size_t lds_cap = want_occ == 2 ? DECNET_LDS_BYTES / 2 : DECNET_LDS_BYTES;
+    const int ku_cap = want_occ == 2 ? 2 : MAXKU;
     const bool mask = d->sink == DECNET_SINK_MASK;
     const int wgran = (ndec || nwrp) ? 64 : 16;          // generated parts: the unit kind must be wave-uniform
     for (int tw = mask ? 64 : 16; tw <= 512; tw += mask ? 64 : 4) {
         const int wrow = tw + 2 * H0, wpad = round_up(wrow, wgran), pitch = round_up(wrow + 16, 16);
-        if (upg_total * wpad > MAXKU * NLW * 64 || P.naux * wpad > MAXKA * NLW * 64) break;
+        if (upg_total * wpad > ku_cap * NLW * 64 || P.naux * wpad > MAXKA * NLW * 64) break;
         size_t lds = (size_t)3 * G0 * (2 * P.L[0].dil + 2) * pitch * 16;
         for (int l = 0; l + 1 < NL; ++l) lds += (size_t)3 * (2 * P.L[l + 1].dil + 2) * pitch * 16;
-        if (lds + 512 + MAXG0 * 8 * sizeof(void *) + MAXL * 16 * 4 + (size_t)2 * P.naux * pitch * 4 > DECNET_LDS_BYTES) break;
+        if (lds + 512 + MAXG0 * 8 * sizeof(void *) + MAXL * 16 * 4 + (size_t)2 * P.naux * pitch * 4 > lds_cap) break;
         const int strips = ceil_div(W, tw);
         // per row step: the slowest wave group (the split is by MFMA count, see below) + a fixed share for the barrier,
         // the source and the epilogues
@@ -747,6 +756,7 @@ int decnet_chain2d_forward(const decnet_chain_desc *d, void *stream) {
     }
     if (!bestTW) return DECNET_ERR_UNSUPPORTED;
     if (d->force_tw > 0) bestTW = d->force_tw;
+    occ = want_occ;
     const int TW = bestTW;
     P.TW = TW; P.Wrow = TW + 2 * H0; P.Wpad = round_up(P.Wrow, wgran); P.pitch = round_up(P.Wrow + 16, 16);
     int us = 0;
@@ -776,6 +786,7 @@ int decnet_chain2d_forward(const decnet_chain_desc *d, void *stream) {
     P.lds_aux = (int)lds;
     lds += (size_t)2 * P.naux * P.pitch * 4;
     if (lds > DECNET_LDS_BYTES) return DECNET_ERR_UNSUPPORTED;
+    if (lds > DECNET_LDS_BYTES / 2 || us > 2 * NLW * 64) occ = 1;          // (a pinned strip width may not fit twice)
     // ---- waves per layer: minimise the slowest group's MFMAs per row step ----
     {
         int nw[MAXL] = {1, 1, 1};
@@ -797,37 +808,43 @@ int decnet_chain2d_forward(const decnet_chain_desc *d, void *stream) {
         double bc = 1e300;
         for (int r = 4; r <= H; ++r) {
             const double wgs = (double)strips * B * ceil_div(H, r);
-            const double c = ceil(wgs / 256.0) * (r + warm);
+            const double c = ceil(wgs / (256.0 * occ)) * (r + warm);
             if (c < bc - 1e-9) { bc = c; R = r; }
         }
     }
     if (d->force_rows > 0) R = d->force_rows;
     P.debug = d->debug;
-    if (d->debug & 256) fprintf(stderr, "chain2d: TW %d R %d strips %d pitch %d lds %zu units %d waves/layer %d %d %d\n", TW, R, strips, P.pitch, lds, us, P.L[0].nw, P.L[1].nw, P.L[2].nw);
+    if (d->debug & 256) fprintf(stderr, "chain2d: TW %d R %d strips %d pitch %d lds %zu units %d waves/layer %d %d %d occ %d\n", TW, R, strips, P.pitch, lds, us, P.L[0].nw, P.L[1].nw, P.L[2].nw, occ);
     P.R = R;
     const dim3 grid((unsigned)strips, (unsigned)ceil_div(H, R), (unsigned)B);
     if (grid.y > 65535) return DECNET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const i32x4_h *wp = (const i32x4_h *)d->w_packed;
-#define GO(MG, SK)                                                                                                      \
+#define GO(SK, SR, OC)                                                                                                  \
     do {                                                                                                                \
         if (lds > 64 * 1024) {                                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void *)chain2d<MG, SK>,                                           \
+            hipError_t e = hipFuncSetAttribute((const void *)chain2d<SK, SR, OC>,                                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
             if (e != hipSuccess) return (int)e;                                                                         \
         }                                                                                                               \
-        hipLaunchKernelGGL((chain2d<MG, SK>), grid, dim3(THREADS), lds, st, P, wp);                                    \
+        hipLaunchKernelGGL((chain2d<SK, SR, OC>), grid, dim3(THREADS), lds, st, P, wp);                                \
     } while (0)
-#define GOS(MG)                                                                          \
+#define GOO(SK, SR)                                                                      \
     do {                                                                                 \
-        if (P.sink == DECNET_SINK_STORE) GO(MG, DECNET_SINK_STORE);                      \
-        else if (P.sink == DECNET_SINK_MASK) GO(MG, DECNET_SINK_MASK);                   \
-        else GO(MG, DECNET_SINK_BLEND);                                                  \
+        if (occ == 2) GO(SK, SR, 2);                                                     \
+        else GO(SK, SR, 1);                                                              \
     } while (0)
-    if (maxg <= 1) GOS(1);
-    else if (maxg == 2) GOS(2);
-    else GOS(3);
+#define GOS(SR)                                                                          \
+    do {                                                                                 \
+        if (P.sink == DECNET_SINK_STORE) GOO(DECNET_SINK_STORE, SR);                     \
+        else if (P.sink == DECNET_SINK_MASK) GOO(DECNET_SINK_MASK, SR);                  \
+        else GOO(DECNET_SINK_BLEND, SR);                                                 \
+    } while (0)
+    if (ndec) GOS(DECNET_PART_DECONV);
+    else if (nwrp) GOS(DECNET_PART_WARP);
+    else GOS(DECNET_PART_PLAIN);
 #undef GOS
+#undef GOO
 #undef GO
     return decnet_launch_status();
 }

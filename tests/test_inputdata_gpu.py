@@ -3,7 +3,9 @@
 against the REFERENCE graph run on the same pixels with the shipped base_channels=8 network
 (tests/golden/inputdata/*.npz, made by tests/golden/make_inputdata_golden.py from the imported reference).  -m gpu.
 
-Gate per pair: <= 1e-3 px mean abs difference of the final disparity map -- where float32 itself allows it.
+Gates per pair (8 cases: 4 pairs x {init17, fill} weights): (1) the GPU result is as close to the reference graph's
+FLOAT64 run as the reference's own float32 run is (ratio <= 1.25); (2) <= 1e-3 px mean abs difference to the
+reference's float32 run -- where float32 itself allows it.
 Two caveats, both measured rather than assumed:
   * The masks are thresholded sigmoids (SparseDenseNetRefinementMask.py:163-170): a logit
     within float noise of the threshold may flip a bit, which moves that pixel (and, through the refinement
@@ -35,7 +37,8 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 
 CASES = [("Sceneflow", "0006", "init17"), ("KITTI", "000009_10", "init17"), ("real", "00003", "init17"),
-         ("real", "00004", "init17"), ("Sceneflow", "0006", "fill"), ("KITTI", "000009_10", "fill")]
+         ("real", "00004", "init17"), ("Sceneflow", "0006", "fill"), ("KITTI", "000009_10", "fill"),
+         ("real", "00003", "fill"), ("real", "00004", "fill")]
 from flipmap import dirty_map  # noqa: E402
 from spy_util import spamat_spy  # noqa: E402
 
@@ -127,21 +130,44 @@ def test_inputdata_pair_matches_reference_graph(ds_name, name, variant):
             print("           SpaMat output on %d unflipped active pixels: mean %.2e max %.2e px" % (ok.sum(), es.mean(),
                                                                                                   es.max()))
             assert es.mean() < 2e-4 and es.max() < 5e-3
-    clean = ~dirty[s3]
-    err = np.abs(pred[s3] - d["pred_s3"])
-    print("  final: mean abs diff %.2e px over the %.1f%% pixels outside flip neighbourhoods (max %.2e); all pixels %.2e; "
-          "|pred| mean %.1f" % (err[clean].mean() if clean.any() else -1, 100 * clean.mean(), err[clean].max()
-                                if clean.any() else -1, err.mean(), float(d["pred_abs_mean"])))
-    noise = float(d["ref_fp32_noise"])
-    gate = max(1e-3, 2 * noise)
-    print("         the reference's own float32-vs-float64 difference on this pair: %.2e px -> gate %.2e px"
-          % (noise, gate))
+    # Three float32 / float64 runs of the same graph on the same pixels: this repo (GPU), the reference in float32 and
+    # the reference in float64 (the "truth" both float32 runs scatter around; fixture keys pred64_s3, *mask*_64).
+    # Pixels in reach of a mask bit that differs between ANY two of them are set aside (a flipped bit moves its
+    # neighbourhood by whole pixels in all three comparisons alike).
+    flips64 = {}
+    for i in range(1, n_stages + 1):
+        shp = tuple(int(v) for v in d["lmask%d_shape" % i])
+        l64 = np.unpackbits(d["lmask%d_64" % i], axis=-1)[..., :shp[-1]].astype(bool).reshape(shp)
+        r64 = np.unpackbits(d["rmask%d_64" % i], axis=-1)[..., :shp[-1]].astype(bool).reshape(shp)
+        flips64[i] = (flips[i][0] | (l64 != _unpack(d, "lmask%d" % i)), flips[i][1] | (r64 != _unpack(d, "rmask%d" % i)))
+    dirty64, _ = dirty_map(flips64, model.max_disp, H, W)
+    clean = ~dirty64[s3]
+    err = np.abs(pred[s3] - d["pred_s3"])                               # vs the reference's float32 run
+    e_gpu64 = np.abs(pred[s3].astype(np.float64) - d["pred64_s3"])      # vs the float64 run
+    e_ref64 = np.abs(d["pred_s3"].astype(np.float64) - d["pred64_s3"])  # the reference's own float32 run vs float64
     assert clean.mean() > 0.5, "too many mask flips to judge the disparity map"
+    g64, r64m = float(e_gpu64[clean].mean()), float(e_ref64[clean].mean())
+    print("  final: |gpu - ref32| mean %.2e px over the %.1f%% pixels outside flip neighbourhoods (max %.2e); all pixels "
+          "%.2e; |pred| mean %.1f" % (err[clean].mean(), 100 * clean.mean(), err[clean].max(), err.mean(),
+                                       float(d["pred_abs_mean"])))
+    print("         distance to the float64 run: gpu %.2e px, the reference's own float32 run %.2e px (ratio %.2f); "
+          "all pixels: gpu %.2e, reference %.2e" % (g64, r64m, g64 / max(r64m, 1e-12), e_gpu64.mean(), e_ref64.mean()))
+    # (1) as close to the truth as the reference's own float32 arithmetic is (25 % + 2e-5 px slack)
+    assert g64 <= 1.25 * r64m + 2e-5, "further from the float64 run than the reference's float32 run is"
+    # (2) north_star's plain gate, 1e-3 px mean against the reference's float32 run, wherever float32 itself allows it:
+    #     two float32 runs that are each e from the truth differ by up to ~2 e, so the plain gate is asserted when the
+    #     reference's own float32 noise is below 4e-4 px (every "fill" pair but real/00004 at max_disp 621) and
+    #     replaced by 1e-3 + 2 x that noise otherwise (the untrained init17 network amplifies rounding, see above)
+    gate = 1e-3 if r64m < 4e-4 else 1e-3 + 2 * r64m
+    print("         gate vs the reference's float32 run: %.2e px (%s)" % (gate, "plain 1e-3" if gate == 1e-3 else
+                                                                            "1e-3 + 2 x reference noise"))
     assert err[clean].mean() < gate
+    if variant == "fill" and r64m < 4e-4:
+        assert err.mean() < 2e-3, "all-pixel mean (flip neighbourhoods included)"
     # the written image: x256 uint16 (demo.py:191-197); one count = 1/256 px
     dp = np.abs(png.astype(np.int64)[s3] - d["pred_png_s3"].astype(np.int64))
     oh, ow = png.shape
-    cl = dirty[-oh:, -ow:][s3]
+    cl = dirty64[-oh:, -ow:][s3]
     print("  png: mean |difference| %.3f counts, %.3f%% of the sampled counts differ by more than 1, outside flip "
           "neighbourhoods" % (dp[~cl].mean(), 100 * (dp[~cl] > 1).mean()))
     assert dp[~cl].mean() < 256 * gate + 0.5      # both sides truncate to 1/256 px
