@@ -41,6 +41,7 @@ SIGNATURES = {
     "decnet_unfold3_cat": [_P] * 3 + [_I] * 4 + [_P],
     "decnet_detail_mask": [_P] * 6 + [_F] * 3 + [_P] * 3 + [_I] * 3 + [_P],
     "decnet_conv2d_cat_bn_act": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P],
+    "decnet_conv2d_cat_epilogue": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P, _P, _P],
     "decnet_conv2d_mfma_packed_bytes": [_I] * 3,
     "decnet_conv2d_mfma_pack_weight": [_P, _P] + [_I] * 3 + [_P],
     "decnet_conv2d_mfma_cat_bn_act": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P],

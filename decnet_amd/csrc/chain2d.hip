@@ -69,10 +69,14 @@ struct PlanK {
 };
 
 __device__ __forceinline__ void split3(float x, int &h, int &m, int &l) {
-    h = __float_as_int(x) & 0xffff0000;
+    // round-to-nearest-even terms (v_cvt_pk_bf16_f32): |x - h| <= 2^-9 |x|, |x - h - m| <= 2^-18 |x|, and the residual
+    // that l leaves is <= 2^-27 |x| -- truncated terms (round 2) left 2^-24 and, worse, always of the sign of x, so the
+    // dropped m.l / l.m products of a K-long sum added up instead of averaging out (tests/test_inputdata_gpu.py measures
+    // the network's distance to its float64 run: 1.35 x the reference's float32 distance before, 1.0 x after)
+    h = __float_as_int((float)(__bf16)x);
     const float r1 = x - __int_as_float(h);
-    m = __float_as_int(r1) & 0xffff0000;
-    l = __float_as_int(r1 - __int_as_float(m));
+    m = __float_as_int((float)(__bf16)r1);
+    l = __float_as_int((float)(__bf16)(r1 - __int_as_float(m)));
 }
 __device__ __forceinline__ int pack2(int hi_elem, int lo_elem) {       // (elem j+1, elem j) -> one dword of bf16 pairs
     return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302);
@@ -731,32 +735,35 @@ int decnet_chain2d_forward(const decnet_chain_desc *d, void *stream) {
     const int upg_total = [&] { int u = 0; for (int g = 0; g < G0; ++g) u += P.gkind[g] == DECNET_PART_DECONV ? 2 : 1; return u; }();
     double best = 1e300;
     int bestTW = 0, occ = 1;
-    // two workgroups per CU (16 waves, <= 128 registers) unless a layer needs 27 weight tiles in registers
+    // two workgroups per CU (16 waves, <= 128 registers) unless a layer needs 27 weight tiles in registers or the
+    // source is too wide for two units per loader lane; else one
     int want_occ = 2;
     for (int l = 0; l < NL; ++l)
         if (P.L[l].KT == 9 && P.L[l].G == 3) want_occ = 1;
     if (d->debug & 32) want_occ = 1;
-    const size_t lds_cap = want_occ == 2 ? DECNET_LDS_BYTES / 2 : DECNET_LDS_BYTES;
-    const int ku_cap = want_occ == 2 ? 2 : MAXKU;
     const bool mask = d->sink == DECNET_SINK_MASK;
     const int wgran = (ndec || nwrp) ? 64 : 16;          // generated parts: the unit kind must be wave-uniform
-    for (int tw = mask ? 64 : 16; tw <= 512; tw += mask ? 64 : 4) {
-        const int wrow = tw + 2 * H0, wpad = round_up(wrow, wgran), pitch = round_up(wrow + 16, 16);
-        if (upg_total * wpad > ku_cap * NLW * 64 || P.naux * wpad > MAXKA * NLW * 64) break;
-        size_t lds = (size_t)3 * G0 * (2 * P.L[0].dil + 2) * pitch * 16;
-        for (int l = 0; l + 1 < NL; ++l) lds += (size_t)3 * (2 * P.L[l + 1].dil + 2) * pitch * 16;
-        if (lds + 512 + MAXG0 * 8 * sizeof(void *) + MAXL * 16 * 4 + (size_t)2 * P.naux * pitch * 4 > lds_cap) break;
-        const int strips = ceil_div(W, tw);
-        // per row step: the slowest wave group (the split is by MFMA count, see below) + a fixed share for the barrier,
-        // the source and the epilogues
-        double mf = 0;
-        for (int l = 0; l < NL; ++l) mf += (double)ceil_div(tw + 2 * P.L[l].halo, 16) * P.L[l].KT * P.L[l].G;
-        const double cost = strips * (mf / NCW * 1.25 + 12.0 + 0.02 * upg_total * wpad);
-        if (cost < best) { best = cost; bestTW = tw; }
+    for (; want_occ >= 1 && !bestTW; --want_occ) {
+        const size_t lds_cap = want_occ == 2 ? DECNET_LDS_BYTES / 2 : DECNET_LDS_BYTES;
+        const int ku_cap = want_occ == 2 ? 2 : MAXKU;
+        for (int tw = mask ? 64 : 16; tw <= 512; tw += mask ? 64 : 4) {
+            const int wrow = tw + 2 * H0, wpad = round_up(wrow, wgran), pitch = round_up(wrow + 16, 16);
+            if (upg_total * wpad > ku_cap * NLW * 64 || P.naux * wpad > MAXKA * NLW * 64) break;
+            size_t lds = (size_t)3 * G0 * (2 * P.L[0].dil + 2) * pitch * 16;
+            for (int l = 0; l + 1 < NL; ++l) lds += (size_t)3 * (2 * P.L[l + 1].dil + 2) * pitch * 16;
+            if (lds + 512 + MAXG0 * 8 * sizeof(void *) + MAXL * 16 * 4 + (size_t)2 * P.naux * pitch * 4 > lds_cap) break;
+            const int strips = ceil_div(W, tw);
+            // per row step: the slowest wave group (the split is by MFMA count, see below) + a fixed share for the
+            // barrier, the source and the epilogues
+            double mf = 0;
+            for (int l = 0; l < NL; ++l) mf += (double)ceil_div(tw + 2 * P.L[l].halo, 16) * P.L[l].KT * P.L[l].G;
+            const double cost = strips * (mf / NCW * 1.25 + 12.0 + 0.02 * upg_total * wpad);
+            if (cost < best) { best = cost; bestTW = tw; }
+        }
+        if (bestTW) { occ = want_occ; break; }
     }
     if (!bestTW) return DECNET_ERR_UNSUPPORTED;
     if (d->force_tw > 0) bestTW = d->force_tw;
-    occ = want_occ;
     const int TW = bestTW;
     P.TW = TW; P.Wrow = TW + 2 * H0; P.Wpad = round_up(P.Wrow, wgran); P.pitch = round_up(P.Wrow + 16, 16);
     int us = 0;

@@ -53,10 +53,14 @@ __host__ __device__ inline int padded_nt(int Cout) {
 }
 
 __device__ __forceinline__ void split3(float x, int &h, int &m, int &l) {
-    h = __float_as_int(x) & 0xffff0000;
+    // round-to-nearest-even terms (v_cvt_pk_bf16_f32): |x - h| <= 2^-9 |x|, |x - h - m| <= 2^-18 |x|, and the residual
+    // that l leaves is <= 2^-27 |x| -- truncated terms (round 2) left 2^-24 and, worse, always of the sign of x, so the
+    // dropped m.l / l.m products of a K-long sum added up instead of averaging out (tests/test_inputdata_gpu.py measures
+    // the network's distance to its float64 run: 1.35 x the reference's float32 distance before, 1.0 x after)
+    h = __float_as_int((float)(__bf16)x);
     const float r1 = x - __int_as_float(h);
-    m = __float_as_int(r1) & 0xffff0000;
-    l = __float_as_int(r1 - __int_as_float(m));
+    m = __float_as_int((float)(__bf16)r1);
+    l = __float_as_int((float)(__bf16)(r1 - __int_as_float(m)));
 }
 
 // w [Cout][Cin][KT] -> wp[chunk][tap][j][n tile][lane] (16 bytes: the lane's 8 bf16 of the B operand)

@@ -37,7 +37,8 @@ template <int CO, int K>
 __global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__restrict__ w,
                                                     const float *__restrict__ scale,
                                                     const float *__restrict__ shift, float *__restrict__ y,
-                                                    int Cout, int H, int W, int dil, int relu, int nrows) {
+                                                    int Cout, int H, int W, int dil, int relu, int nrows, int epi,
+                                                    const float *__restrict__ ea, const float *__restrict__ eb) {
     int bx, row;
     if (!decnet_xcd_rows((W + 1023) >> 10, nrows, bx, row)) return;      // rows of one XCD's blocks are neighbours
     const int x0 = (bx * 256 + threadIdx.x) * 4, b = row / H, yy = row - b * H;
@@ -92,6 +93,24 @@ __global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__rest
             for (int e = 0; e < 4; ++e) {
                 o[e] = fmaf(acc[co][e], sc, sh);
                 if (relu) o[e] = fmaxf(o[e], 0.f);
+            }
+            if (CO == 1 && epi) {
+#pragma clang fp contract(off)
+                // single-output layers with the elementwise tail of their caller fused (ea, eb: [B,H,W] planes):
+                //   1: SoftAttention + fusion (SparseDenseNetRefinementMask.py:195-202): s = sigmoid(o); ea (1 - s) + s eb
+                //   2: Refinement's residual (submodule.py:716): ea + o
+                const size_t pix = (size_t)b * plane + (size_t)yy * W + x0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (x0 + e >= W) continue;
+                    if (epi == 1) {
+                        const float sft = 1.f / (1.f + expf(-o[e]));
+                        const float t1 = ea[pix + e] * (1.f - sft), t2 = sft * eb[pix + e];
+                        o[e] = t1 + t2;
+                    } else {
+                        o[e] = ea[pix + e] + o[e];
+                    }
+                }
             }
             float *yp = y + ((size_t)b * Cout + co) * plane + (size_t)yy * W + x0;
             if (vec) {
@@ -231,14 +250,15 @@ __global__ __launch_bounds__(256) void bias_act_inplace(float *__restrict__ y, c
 
 template <int CO>
 int launch_conv(const Segs &in, const float *w, const float *scale, const float *shift, float *y, int B,
-                int Cout, int H, int W, int k, int dil, int relu, hipStream_t s) {
+                int Cout, int H, int W, int k, int dil, int relu, hipStream_t s, int epi = 0, const float *ea = nullptr,
+                const float *eb = nullptr) {
     const dim3 grid(decnet_xcd_grid(ceil_div(W, 1024), (long)H * B));
     if (k == 3)
         hipLaunchKernelGGL((conv2d_small<CO, 3>), grid, dim3(256), 0, s, in, w, scale, shift, y, Cout, H, W, dil,
-                           relu, H * B);
+                           relu, H * B, epi, ea, eb);
     else
         hipLaunchKernelGGL((conv2d_small<CO, 1>), grid, dim3(256), 0, s, in, w, scale, shift, y, Cout, H, W, dil,
-                           relu, H * B);
+                           relu, H * B, epi, ea, eb);
     return decnet_launch_status();
 }
 
@@ -340,7 +360,8 @@ __global__ __launch_bounds__(256) void dynamic_upsample3(const float *__restrict
 }
 
 static int conv2d_segs(const Segs &in, const float *w, const float *scale, const float *shift, float *y, int B,
-                       int Cout, int H, int W, int k, int dilation, int relu, void *stream) {
+                       int Cout, int H, int W, int k, int dilation, int relu, void *stream, int epi = 0,
+                       const float *ea = nullptr, const float *eb = nullptr) {
     if (!w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
     if ((k != 1 && k != 3) || Cout > 24 || H > 65535 || B > 65535 || W > (1 << 28) ||
@@ -353,7 +374,8 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
     }
     if ((double)B * (cin > Cout ? cin : Cout) * H * W >= 9.0e18) return DECNET_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (Cout <= 1) return launch_conv<1>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
+    if (epi && (Cout != 1 || !ea || (epi == 1 && !eb) || epi < 0 || epi > 2)) return DECNET_ERR_UNSUPPORTED;
+    if (Cout <= 1) return launch_conv<1>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s, epi, ea, eb);
     if (Cout <= 4) return launch_conv<4>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
     if (Cout <= 8) return launch_conv<8>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
     return launch_conv<24>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);   // co_pad(Cout) = 24
@@ -376,6 +398,17 @@ int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, 
     for (int i = 0; i < nseg; ++i) { in.p[i] = xs[i]; in.c[i] = cins[i]; }
     in.n = nseg;
     return conv2d_segs(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, stream);
+}
+
+int decnet_conv2d_cat_epilogue(const float *const *xs, const int *cins, int nseg, const float *w, const float *scale,
+                               const float *shift, float *y, int B, int H, int W, int k, int dilation, int relu,
+                               int epilogue, const float *ea, const float *eb, void *stream) {
+    if (!xs || !cins) return DECNET_ERR_NULL_POINTER;
+    if (nseg < 1 || nseg > MAXSEG) return DECNET_ERR_UNSUPPORTED;
+    Segs in{};
+    for (int i = 0; i < nseg; ++i) { in.p[i] = xs[i]; in.c[i] = cins[i]; }
+    in.n = nseg;
+    return conv2d_segs(in, w, scale, shift, y, B, 1, H, W, k, dilation, relu, stream, epilogue, ea, eb);
 }
 
 int decnet_dynamic_upsample3(const float *logits, const float *disp, float *out, int B, int h, int w,

@@ -56,20 +56,25 @@ class Unit(nn.Module):
         c = self.conv
         # many channels: the bf16x3 matrix-core kernel (csrc/conv2d_mfma.hip) where the image gives it enough
         # workgroups (>= 4096 pixels, e.g. the 60 x 108 level; at 20 x 36 the library's kernels win)
-        if (isinstance(c, nn.Conv2d) and c.out_channels >= 24 and c.in_channels >= 16 and c.kernel_size in ((1, 1), (3, 3)) and
+        if (isinstance(c, nn.Conv2d) and (c.out_channels >= 24 or c.in_channels >= 48) and c.in_channels >= 16 and
+                c.kernel_size in ((1, 1), (3, 3)) and
                 c.stride == (1, 1) and c.dilation[0] == c.dilation[1] and c.groups == 1 and c.padding_mode == "zeros" and
                 c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and x.shape[-1] * x.shape[-2] >= 4096 and
                 c.dilation[0] <= 4 and os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma"
         # transposed convolution k = 3, stride 3 with more than 8 output channels: the same kernel, as a 1 x 1 convolution
         # to 9 Cout channels with a pixel-shuffle store
-        if (isinstance(c, nn.ConvTranspose2d) and c.out_channels > 8 and c.in_channels >= 16 and c.kernel_size == (3, 3) and
+        if (isinstance(c, nn.ConvTranspose2d) and (c.out_channels > 8 or c.in_channels >= 64) and c.in_channels >= 16 and
+                c.kernel_size == (3, 3) and
                 c.stride == (3, 3) and c.padding == (0, 0) and c.output_padding == (0, 0) and c.dilation == (1, 1) and
                 c.groups == 1 and x.shape[-1] * x.shape[-2] >= 512 and
                 os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma_deconv"
+        # the few-channel kernels at every size (at 60 x 108 and 20 x 36 they do not fill the chip, but one launch
+        # replaces the library's convolution + layout transposes + bias / ReLU passes); DECNET_SMALL_MIN_PIXELS=16384
+        # restores round 2's threshold
         up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
-        if x.shape[-1] * x.shape[-2] * up < 16384:
+        if x.shape[-1] * x.shape[-2] * up < int(os.environ.get("DECNET_SMALL_MIN_PIXELS", "256")):
             return None
         if (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (1, 1) and
                 c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros" and c.out_channels <= 24):
@@ -87,12 +92,13 @@ class Unit(nn.Module):
               c.padding == (c.dilation[0] * (k // 2),) * 2 and c.groups == 1 and c.padding_mode == "zeros")
         return "conv" if ok else None
 
-    def _folded(self):
-        """Per-channel scale / shift of the eval-mode BatchNorm (or 1 / bias), cached per weight version."""
+    def _folded(self, neg_last=False):
+        """Per-channel scale / shift of the eval-mode BatchNorm (or 1 / bias), cached per weight version.
+        neg_last: the weights of the last input channel negated (a caller that feeds -x passes x instead)."""
         c, bn = self.conv, self.bn
         ts = [c.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else
                            ([c.bias] if c.bias is not None else []))
-        key = tuple((t.data_ptr(), t._version) for t in ts)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (bool(neg_last),)
         if getattr(self, "_fold_key", None) != key:
             with torch.no_grad():
                 co = c.out_channels
@@ -106,6 +112,9 @@ class Unit(nn.Module):
                 L = _lib.lib()
                 tr = 1 if isinstance(c, nn.ConvTranspose2d) else 0
                 w = c.weight.detach().float().contiguous()
+                if neg_last:
+                    w = w.clone()
+                    w[:, -1] = -w[:, -1]
                 k = c.kernel_size[0]
                 wp = torch.empty(L.decnet_conv2d_packed_floats(c.in_channels, co, k, tr), dtype=torch.float32,
                                  device=w.device)
@@ -185,24 +194,35 @@ class Unit(nn.Module):
         _lib.check(rc, "decnet_deconv2d_mfma_k3s3_bn_act")
         return y
 
-    def _forward_hip(self, x, kind):
+    def _forward_hip(self, x, kind, out=None, epi=0, ea=None, eb=None, neg_last=False):
+        """out: write into this [B,Cout,H,W] buffer (kind "conv"); epi / ea / eb: decnet_conv2d_cat_epilogue's fused tail
+        of a single-output layer; neg_last: see _folded."""
         if kind == "mfma":
             return self._forward_mfma(x)
         if kind == "mfma_deconv":
             return self._forward_mfma_deconv(x)
         from . import _lib
         from .ops import _stream
-        w, scale, shift = self._folded()
-        if isinstance(x, (tuple, list)):                # concatenated input, never materialised
+        w, scale, shift = self._folded(neg_last)
+        if isinstance(x, (tuple, list)) or epi:         # concatenated input, never materialised
             import ctypes
-            xs = [t.contiguous() for t in x]
+            xs = [t.contiguous() for t in (x if isinstance(x, (tuple, list)) else (x,))]
             B, _, H, W = xs[0].shape
             Co = self.conv.out_channels
             assert sum(t.shape[1] for t in xs) == self.conv.in_channels
-            y = torch.empty((B, Co, H, W), dtype=torch.float32, device=xs[0].device)
+            y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=xs[0].device)
             ptrs = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
             cins = (ctypes.c_int * len(xs))(*[int(t.shape[1]) for t in xs])
             with torch.cuda.device(y.device):
+                if epi:
+                    assert Co == 1 and ea.is_contiguous() and (eb is None or eb.is_contiguous())
+                    rc = _lib.lib().decnet_conv2d_cat_epilogue(ptrs, cins, len(xs), w.data_ptr(), scale.data_ptr(),
+                                                               shift.data_ptr(), y.data_ptr(), B, H, W,
+                                                               self.conv.kernel_size[0], self.conv.dilation[0],
+                                                               1 if self.relu else 0, int(epi), ea.data_ptr(),
+                                                               eb.data_ptr() if eb is not None else None, _stream(y))
+                    _lib.check(rc, "decnet_conv2d_cat_epilogue")
+                    return y
                 rc = _lib.lib().decnet_conv2d_cat_bn_act(ptrs, cins, len(xs), w.data_ptr(), scale.data_ptr(),
                                                          shift.data_ptr(), y.data_ptr(), B, Co, H, W,
                                                          self.conv.kernel_size[0], self.conv.dilation[0],
@@ -224,7 +244,8 @@ class Unit(nn.Module):
                                                    y.data_ptr(), B, Cin, Co, H, W, 1 if self.relu else 0,
                                                    _stream(x))
             else:
-                y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+                y = out if out is not None else torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+                assert y.is_contiguous()
                 rc = L.decnet_conv2d_bn_act(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                             y.data_ptr(), B, Cin, Co, H, W, self.conv.kernel_size[0],
                                             self.conv.dilation[0], 1 if self.relu else 0, _stream(x))
@@ -416,8 +437,23 @@ class FeatExtNetChannelPlus(nn.Module):
         self.deconv3 = UpBlock(c3, c2)
         self.out_channels = [c3, c2, c1, c]
 
-    def forward(self, x):
-        f0 = self.conv0(x)
+    def forward(self, x, x2=None):
+        """x2: a second image batch (the right views); the result is that of forward(cat(x, x2)) -- every op is
+        per-sample in eval mode -- without materialising the concatenation: the first convolution writes the two
+        halves of one output buffer."""
+        if x2 is not None:
+            u0 = self.conv0[0]
+            kind = u0._hip_kind(x)
+            if kind == "conv" and x.shape == x2.shape:
+                nb = x.shape[0]
+                y = torch.empty((2 * nb, u0.conv.out_channels) + tuple(x.shape[-2:]), dtype=torch.float32, device=x.device)
+                u0._forward_hip(x, kind, out=y[:nb])
+                u0._forward_hip(x2, kind, out=y[nb:])
+                f0 = self.conv0[1](y)
+            else:
+                f0 = self.conv0(torch.cat([x, x2]))
+        else:
+            f0 = self.conv0(x)
         f1 = self.conv1(f0)
         f2 = self.conv2(f1)
         f3a = self.conv3_1(f2)
@@ -544,6 +580,28 @@ class SoftAttention(nn.Module):
     def forward(self, x):
         return torch.sigmoid(self.conv(x))
 
+    def fuse(self, fea, dense, sparse, mask, var):
+        """The attention and the fusion of the stage loop (SparseDenseNetRefinementMask.py:195-202) in one go:
+        soft = self(cat(fea, dense, sparse, mask, -var)); dense * (1 - soft) + soft * sparse.  On the GPU the
+        concatenation, the negation (folded into the first layer's weights), the sigmoid and the blend are part
+        of the three convolution launches."""
+        parts = (fea, dense.unsqueeze(1), sparse.unsqueeze(1), mask.unsqueeze(1), var.unsqueeze(1))
+        u0, u1, u2 = self.conv[0], self.conv[1], self.conv[2]
+        k0 = u0._hip_kind(parts)
+        if (k0 in ("conv", "mfma") and u2.conv.out_channels == 1 and not u2.relu and
+                os.environ.get("DECNET_FUSE_TAILS", "1") == "1"):
+            if k0 == "conv":
+                t = u0._forward_hip(parts, "conv", neg_last=True)
+            else:                                       # many input channels (1/9, 1/3 resolution): matrix-core kernel
+                t = u0._forward_hip(parts[:4] + (-var.unsqueeze(1),), "mfma")
+            t = u1(t)
+            if u2._hip_kind(t) == "conv":
+                return u2._forward_hip(t, "conv", epi=1, ea=dense.contiguous(), eb=sparse.contiguous()).squeeze(1)
+            soft = torch.sigmoid(u2(t)).squeeze(1)
+            return dense * (1 - soft) + soft * sparse
+        soft = self(parts[:4] + (-var.unsqueeze(1),)).squeeze(1)
+        return dense * (1 - soft) + soft * sparse
+
 
 def warp_by_disparity(right, disp):
     """Refinement.get_warped_feats_by_homgrp (submodule.py:719-745): the same stretched,
@@ -580,7 +638,17 @@ class Refinement(nn.Module):
                          _c3(h, 1, relu=False, bn=False))
 
     def forward(self, left, right, disp):
-        res = self.conv((left, warp_by_disparity(right, disp), disp.unsqueeze(1))).squeeze(1)
+        x = (left, warp_by_disparity(right, disp), disp.unsqueeze(1))
+        last = self.conv[-1]
+        if os.environ.get("DECNET_FUSE_TAILS", "1") == "1" and last.conv.out_channels == 1:
+            t = x
+            for u in list(self.conv)[:-1]:
+                t = u(t)
+            if last._hip_kind(t) == "conv":             # disp + res as the last layer's epilogue (reference :716)
+                return last._forward_hip(t, "conv", epi=2, ea=disp.contiguous()).squeeze(1), None
+            res = last(t).squeeze(1)
+            return disp + res, res
+        res = self.conv(x).squeeze(1)
         return disp + res, res
 
 
@@ -633,10 +701,11 @@ class SparseDenseNetRefinementMask(nn.Module):
                 is_check=False, is_eval=False):
         if self.training:
             raise NotImplementedError("inference only: call .eval() (SURVEY.md S11)")
+        f2 = None
         if left.is_cuda and left.shape == right.shape and os.environ.get("DECNET_FEAT_BATCH", "1") == "1":
             # both views in one pass (per-sample ops, eval BN: same result; the 1/9 and 1/27 layers
             # are too small at B pairs to fill 256 CUs)
-            f2 = self.feature_extractor(torch.cat([left, right]))
+            f2 = self.feature_extractor(left, right)
             nb = left.shape[0]
             lf = {k: v[:nb] for k, v in f2.items()}
             rf = {k: v[nb:] for k, v in f2.items()}
@@ -659,8 +728,18 @@ class SparseDenseNetRefinementMask(nn.Module):
                 continue
             if self.use_detail:                                           # reference :148-170
                 gen = self.detail_detection[stage - 1]
-                lmask, lbits = gen.mask(L, pre_L, self.thold, want_bits=True)
-                rmask, rbits = gen.mask(R, pre_R, self.thold, want_bits=True)
+                # both views as one batch of 2 B samples where the levels are launch-bound (1/9, 1/3 resolution); at full
+                # resolution a [16,8,540,972] tensor is 268 MB -- more than the 256 MiB Infinity Cache that keeps a
+                # view's 134 MB intermediates on chip between producer and consumer (measured: 656 vs 608 us)
+                if f2 is not None and 2 * L.numel() * 4 <= (96 << 20):
+                    cur2, pre2 = f2["stage%d" % stage], f2["stage%d" % (stage - 1)]
+                    m2, b2 = gen.mask(cur2, pre2, self.thold, want_bits=True)
+                    nb = L.shape[0]
+                    lmask, rmask = m2[:nb], m2[nb:]
+                    lbits, rbits = (b2[:nb], b2[nb:]) if b2 is not None else (None, None)
+                else:
+                    lmask, lbits = gen.mask(L, pre_L, self.thold, want_bits=True)
+                    rmask, rbits = gen.mask(R, pre_R, self.thold, want_bits=True)
                 pre_L, pre_R = L, R
             else:
                 lmask, rmask = left_mask_list[stage - 1], right_mask_list[stage - 1]
@@ -681,9 +760,7 @@ class SparseDenseNetRefinementMask(nn.Module):
             else:
                 sparse, var, _, _ = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(),
                                                       rmask.contiguous(), cur_max_disp)
-            soft = self.soft_attention[stage - 1](
-                (L, dense.unsqueeze(1), sparse.unsqueeze(1), lmask.unsqueeze(1), -var.unsqueeze(1))).squeeze(1)
-            fused = dense * (1 - soft) + soft * sparse                    # reference :202
+            fused = self.soft_attention[stage - 1].fuse(L, dense, sparse, lmask, var)     # reference :195-202
             pred, _ = self.refinement[stage - 1](L, R, fused)             # reference :207
         return [pred]
 

@@ -227,6 +227,14 @@ int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *sca
  * (host arrays of device pointers / channel counts; weights packed for Cin = sum of cins): the
  * torch.cat in front of the Deconv2dBlock / Refinement / SoftAttention convolutions
  * (submodule.py:176, 755, SparseDenseNetRefinementMask.py:195-199) is never materialised. */
+/* decnet_conv2d_cat_bn_act for a layer with ONE output channel, with the elementwise tail of its caller fused
+ * (ea, eb: [B,H,W] planes; y [B,1,H,W]):
+ *   epilogue 1  SoftAttention's last layer + the fusion of the stage loop (submodule.py:593-604,
+ *               SparseDenseNetRefinementMask.py:195-202): s = sigmoid(conv), y = ea (1 - s) + s eb   (ea dense, eb sparse)
+ *   epilogue 2  Refinement's last layer + residual (submodule.py:716): y = ea + conv                             */
+int decnet_conv2d_cat_epilogue(const float *const *xs, const int *cins, int nseg, const float *w_packed,
+                               const float *scale, const float *shift, float *y, int B, int H, int W, int k,
+                               int dilation, int relu, int epilogue, const float *ea, const float *eb, void *stream);
 int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, const float *w_packed,
                              const float *scale, const float *shift, float *y, int B, int Cout, int H,
                              int W, int k, int dilation, int relu, void *stream);
