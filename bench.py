@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 matrix peak (v_mfma_f32_*_f32)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 matrix peak (MI355X_MICROARCH.md)
 
 # BASELINE.json configs that fit one process per GPU: (name, padded H, padded W, rounded max_disp, pairs per GPU)
 CONFIGS = {
@@ -301,10 +302,11 @@ def pack_mask_bits(mask):
 
 
 def alt_gemm_leg():
-    """The hot-path step once more in a child process with the opt-in bf16x3 Winograd GEMM (the switch is read once per
-    process and changes the packed weights): value / ms_per_step / GEMM ms of that configuration."""
+    """The hot-path step once more in a child process with the fp32 MFMA Winograd GEMM (DECNET_WINO_GEMM=fp32; the
+    switch is read once per process and changes the packed weights): value / ms_per_step / GEMM ms of round 2's
+    default, beside this round's bf16x3 default."""
     import subprocess
-    env = dict(os.environ, DECNET_WINO_GEMM="bf16x3")
+    env = dict(os.environ, DECNET_WINO_GEMM="fp32")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "50", "--warmup", "8", "--no-cpu-baseline", "--no-train",
            "--no-density-sweep", "--no-e2e", "--no-alt"]
     try:
@@ -312,12 +314,10 @@ def alt_gemm_leg():
         d = json.loads(r.stdout.strip().splitlines()[-1])
         return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                 "wino_gemm_ms": d["roofline"]["ms"],
-                "fp32_equivalent_tflops": d["roofline"]["achieved"],
-                "bf16_pipe_frac": 6.0 * d["roofline"]["achieved"] / 2500.0,
-                "note": "DECNET_WINO_GEMM=bf16x3: every fp32 product of the Winograd GEMMs as six bf16 products on "
-                        "v_mfma_f32_16x16x32_bf16, fp32 accumulation; tests/conv_numerics.py: 4.7e-6 relative error on "
-                        "the regularised volume against 5.7e-6 for the fp32 MFMA path.  bf16_pipe_frac = executed bf16 "
-                        "FLOPs / 2.5 PFLOP/s"}
+                "fp32_tflops": d["roofline"]["fp32_equivalent_tflops"],
+                "fp32_mfma_frac": d["roofline"]["fp32_equivalent_tflops"] / MFMA_F32_PEAK_TF,
+                "note": "DECNET_WINO_GEMM=fp32: the Winograd GEMMs on v_mfma_f32_16x16x4_f32 (wino_gemm_persist), the "
+                        "default of rounds 1-2; fp32_mfma_frac = its flops / the 157.3 TFLOP/s fp32 MFMA peak"}
     except Exception as e:  # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
@@ -604,9 +604,8 @@ def main():
                     help="skip the extra 'train' object (config 5: SpaMat forward+backward, stages 1-3)")
     ap.add_argument("--e2e", action="store_true", help="(default at 1 GPU) see --no-e2e")
     ap.add_argument("--no-alt", action="store_true",
-                    help="skip the 'alt_wino_gemm_bf16x3' object: the same hot-path step in a child process with "
-                         "DECNET_WINO_GEMM=bf16x3 (the Winograd GEMMs as bf16x3 products on the bf16 matrix cores, same "
-                         "accuracy; not the default, so that `roofline` prices plain fp32 MFMA arithmetic)")
+                    help="skip the 'alt_wino_gemm_fp32' object: the same hot-path step in a child process with "
+                         "DECNET_WINO_GEMM=fp32 (the Winograd GEMMs on fp32 MFMA, round 2's default)")
     ap.add_argument("--no-valu-floor", action="store_true",
                     help="skip the live VALU-floor microbenchmark (a child process; profiling runs)")
     ap.add_argument("--force-collective", action="store_true",
@@ -701,6 +700,7 @@ def main():
             L = _lib.lib()
             st = torch.cuda.current_stream().cuda_stream
             p0 = P[0]
+            gemm_mult, gemm_peak, gemm_arith = 1.0, MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_16x16x4_f32)"
             if conv_algo(D0) in WINO_VARIANT:
                 # one Conv3d layer = input transform + batched GEMMs (one per transform point) + output
                 # transform; the GEMM kernel (wino_gemm) is the dominant kernel of the step
@@ -716,8 +716,14 @@ def main():
                 conv_ms = time_kernel(lambda: L.decnet_conv3d_wino_gemm(
                     V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, var, st), 60)
                 kern_flop = 2.0 * npts * nt * C0 * C0
-                kern_name = "wino_gemm (%d x [%d x %d] x [%d x %d], %s Conv3d 216->216)" % (
-                    npts, nt, C0, C0, C0, ("Winograd F(2,3)^3", "Winograd F(2,3)xF(4,3)^2", "Winograd F(4,3)^3")[var])
+                bf16x3 = C0 == 216 and os.environ.get("DECNET_WINO_GEMM", "") in ("", "bf16x3")
+                if bf16x3:
+                    gemm_mult, gemm_peak = 6.0, MFMA_BF16_PEAK_TF
+                    gemm_arith = "fp32 operands as three bf16 terms (round to nearest), six products on " \
+                                 "v_mfma_f32_16x16x32_bf16, fp32 accumulation"
+                kern_name = "%s (%d x [%d x %d] x [%d x %d], %s Conv3d 216->216)" % (
+                    "wino_gemm_bf16x3" if bf16x3 else "wino_gemm", npts, nt, C0, C0, C0,
+                    ("Winograd F(2,3)^3", "Winograd F(2,3)xF(4,3)^2", "Winograd F(4,3)^3")[var])
                 tkey = "wino_gemm"
             else:
                 conv_ms = layer_ms = time_kernel(lambda: L.decnet_conv3d_bn_act(
@@ -785,15 +791,22 @@ def main():
                       " (hot path: stage-0 dense + SpaMat/SpaVar stages 1-3)",
             "value": pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (bf16x3 on the bf16 matrix pipe)" if gemm_mult > 1 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE %s: batch=%d synthetic pairs per GPU, feature maps of the "
                                    "4-stage/scale-3 net, random-init CostRegNetNoDown(216)" % (CONFIG_NAME, B),
                        "pairs_per_gpu": B, "mask_density": args.mask_density,
                        "parallelism": "dp%d (pairs sharded, all_gather of disparity maps)" % world},
-            "roofline": {"bound": "mfma", "achieved": kern_flop / conv_ms / 1e9, "peak": MFMA_F32_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": kern_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
+            # bf16x3 (default at Ci = 216): every fp32 product of the GEMM is executed as six bf16 products on
+            # v_mfma_f32_16x16x32_bf16, so the kernel is priced with its EXECUTED flops (6 x the algorithmic ones)
+            # against the dense bf16 peak; fp32_equivalent_tflops = algorithmic flops / time (157.3 would be the fp32 peak)
+            "roofline": {"bound": "mfma", "achieved": gemm_mult * kern_flop / conv_ms / 1e9, "peak": gemm_peak,
+                         "unit": "TFLOP/s", "frac": gemm_mult * kern_flop / conv_ms / 1e9 / gemm_peak,
                          "traffic": traffic.get(tkey, {}).get("total_bytes"), "kernel": kern_name,
-                         "ms": conv_ms, "flop_per_launch": kern_flop, "stage0_ms_in_step": s0_ms,
+                         "ms": conv_ms, "flop_per_launch": gemm_mult * kern_flop, "algorithmic_flop_per_launch": kern_flop,
+                         "fp32_equivalent_tflops": kern_flop / conv_ms / 1e9,
+                         "fp32_equivalent_frac_of_fp32_mfma_peak": kern_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
+                         "arithmetic": gemm_arith, "stage0_ms_in_step": s0_ms,
                          "conv3d_layer_ms": layer_ms,
                          "conv3d_layer_direct_equiv_tflops": conv_flop / layer_ms / 1e9},
             "roofline_costvol": {"bound": "hbm", "achieved": s3_bytes / s3_ms / 1e6, "peak": HBM_PEAK_GBS,
@@ -839,7 +852,7 @@ def main():
                 out["e2e"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if (world == 1 and not args.no_alt and args.config == 2 and args.mask_density >= 1.0 and
                 os.environ.get("DECNET_WINO_GEMM", "") == ""):
-            out["alt_wino_gemm_bf16x3"] = alt_gemm_leg()
+            out["alt_wino_gemm_fp32"] = alt_gemm_leg()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)

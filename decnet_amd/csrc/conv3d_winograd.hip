@@ -716,11 +716,11 @@ __device__ __forceinline__ void split3(const f32x4 &a, const f32x4 &b, i32x4 &hi
     float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     int h[8], m[8], l[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = __float_as_int(x[e]) & 0xffff0000;
+    for (int e = 0; e < 8; ++e) {                       // round-to-nearest terms (v_cvt_pk_bf16_f32): see csrc/conv2d_mfma.hip
+        h[e] = __float_as_int((float)(__bf16)x[e]);
         const float r1 = x[e] - __int_as_float(h[e]);
-        m[e] = __float_as_int(r1) & 0xffff0000;
-        l[e] = __float_as_int(r1 - __int_as_float(m[e]));
+        m[e] = __float_as_int((float)(__bf16)r1);
+        l[e] = __float_as_int((float)(__bf16)(r1 - __int_as_float(m[e])));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {                       // {x[2e+1][31:16], x[2e][31:16]}
@@ -859,9 +859,11 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
-// 1: bf16x3 GEMM (needs the split copy of U^T behind the fp32 one, see decnet_conv3d_wino_pack_weight)
+// 1: bf16x3 GEMM (needs the split copy of U^T behind the fp32 one, see decnet_conv3d_wino_pack_weight).  The default
+// since round 3 (the same accuracy, 0.113 instead of 0.131 ms per layer at config 2); DECNET_WINO_GEMM=fp32 (or
+// static / any other value) selects the fp32 MFMA kernels.  Read once per process: it fixes the packed weights' size.
 static int gemm_bf16x3() {
-    static const int k = [] { const char *e = getenv("DECNET_WINO_GEMM"); return e && !strcmp(e, "bf16x3") ? 1 : 0; }();
+    static const int k = [] { const char *e = getenv("DECNET_WINO_GEMM"); return !e || !e[0] || !strcmp(e, "bf16x3") ? 1 : 0; }();
     return k;
 }
 
