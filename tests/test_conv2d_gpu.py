@@ -45,6 +45,27 @@ def test_conv_unit_vs_torch_cpu(dev, cin, cout, k, dil, relu, bn):
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("epi", [1, 2])
+def test_single_output_layer_with_fused_tail(dev, epi):
+    """decnet_conv2d_cat_epilogue: epilogue 1 (SoftAttention's sigmoid + the stage loop's dense / sparse fusion,
+    SparseDenseNetRefinementMask.py:195-202) and 2 (Refinement's residual, submodule.py:716) against the torch ops;
+    concatenated input, negated last channel folded into the weights."""
+    u = _unit(12, 1, 3, 1, False, True, seed=77)
+    g = torch.Generator().manual_seed(6)
+    a, b4 = torch.randn(2, 8, 90, 333, generator=g), torch.randn(2, 4, 90, 333, generator=g)
+    ea, eb = torch.randn(2, 90, 333, generator=g) * 30, torch.randn(2, 90, 333, generator=g) * 30
+    with torch.no_grad():
+        xin = torch.cat((a, b4[:, :3], -b4[:, 3:]), 1)
+        v = u(xin).squeeze(1)
+        ref = ea * (1 - torch.sigmoid(v)) + torch.sigmoid(v) * eb if epi == 1 else ea + v
+        ud = u.to(dev)
+        parts = (a.to(dev), b4.to(dev))
+        assert ud._hip_kind(parts) == "conv"
+        got = ud._forward_hip(parts, "conv", epi=epi, ea=ea.to(dev), eb=eb.to(dev) if epi == 1 else None,
+                              neg_last=True).squeeze(1).cpu()
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 # the many-channel layers on the bf16 matrix cores (csrc/conv2d_mfma.hip): every (tile height, channel tile count)
 # variant, concatenated inputs, ragged sizes, dilation, 1x1; reference = torch CPU in float64
 @pytest.mark.parametrize("cins,cout,k,dil,relu,bn,shape,tm", [
