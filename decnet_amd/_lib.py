@@ -39,6 +39,7 @@ SIGNATURES = {
     "decnet_conv2d_k3s3_bn_act": [_P] * 5 + [_I] * 6 + [_P],
     "decnet_bias_act_inplace": [_P, _P] + [_I] * 5 + [_P],
     "decnet_unfold3_cat": [_P] * 3 + [_I] * 4 + [_P],
+    "decnet_s2d3_pad1": [_P, _P] + [_I] * 4 + [_P],
     "decnet_detail_mask": [_P] * 6 + [_F] * 3 + [_P] * 3 + [_I] * 3 + [_P],
     "decnet_conv2d_cat_bn_act": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P],
     "decnet_conv2d_cat_epilogue": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 7 + [_P, _P, _P],

@@ -466,6 +466,14 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
 
 // KQ = number of K=4 channel steps when known at compile time (C <= 4*KQ), 0 = runtime loop.
 // D16: dense rows go through dense16_body (bf16 matrix cores) instead of the fp32 MFMA band path.
+template <int NT, int MODE, int KQ, int PPT, int NTHR, int CAP, int NTCMAX>
+__device__ __forceinline__ int sparse_row_body(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
+    float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
+    int H, int W, int D, int row, int dense_pct, int mbits);
+constexpr int MID_CAP = 512;                            // active pixels per side of a "mid-density" row (marker == 2)
+
 template <int NT, int MODE, int KQ, bool D16>
 __device__ __forceinline__ void spamat_fwd_segment(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
@@ -475,8 +483,21 @@ __device__ __forceinline__ void spamat_fwd_segment(
     // marker: this launch follows spamat_fwd_sparse, which left -1 in sum_sim[row start] of exactly
     // the rows it did not take, at the first pixel of every segment (a real sum_similarities is never
     // negative)
-    if (marker && sum_sim[(size_t)row * W + (size_t)seg * (XT * 16)] != -1.0f)
+    const float mark = marker ? sum_sim[(size_t)row * W + (size_t)seg * (XT * 16)] : -1.0f;
+    if (marker && !(mark < 0.f))
         return;
+    if constexpr (KQ == 2) {
+        // marker == 2 (whole rows per workgroup): a row the sparse-row kernel handed over may still have <= 512 active
+        // pixels per side (densities 0.25-0.5 at stage 3) -- this workgroup runs the same sparse-row algorithm on it,
+        // with 512 slots and NT + 1 tiles, instead of the compact path below
+        if (marker == 2 && mark == -2.0f) {
+            if (sparse_row_body<NT, MODE, KQ, 4, THREADS, MID_CAP, NT + 1>(ref, tar, rmask, tmask, disparity, out, var_out,
+                                                                          sum_sim, max_cost, C, H, W, D, row, compact_pct,
+                                                                          mbits) == 1)
+                return;
+            __syncthreads();                            // its LDS arrays are free again
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Layout lo = make_layout(C, NT, XT, D16);
     float *Rs = smem + lo.offR;
@@ -863,24 +884,33 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
 // Rows that are not sparse enough are left to spamat_fwd_mfma, launched right after with
 // marker = 1: this kernel writes -1 to sum_sim[row start] of exactly those rows.
 constexpr int SP_THREADS = 256, SP_NWAVE = SP_THREADS / 64, SP_CAP = 256, SP_FP = SP_CAP + 16;
+// LDS words of sparse_row_body<.., KQ, PPT, NTHR, CAP, ..>
+constexpr size_t sparse_row_words(int kq, int ppt, int nthr, int cap) {
+    return (size_t)(cap + 16) + 2 * (size_t)(nthr * ppt / 2 + 2) + cap + 32 + 2 * (size_t)4 * kq * (cap + 16);
+}
 
-// PPT = pixels per thread of the mask scan: 4 (W <= 1024) or 8 (W <= 2048).  seg_w = pixels per
-// segment of the marker launch (it splits rows wider than 1024 pixels): one marker per segment.
-template <int NT, int MODE, int KQ, int PPT>
-__global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_sparse(
+// The body: ONE whole image row by a workgroup of NTHR threads (W <= NTHR * PPT), at most CAP active pixels per side and
+// NTCMAX cost tiles per span.  Returns false -- with nothing written -- when the row is not sparse enough for these limits.
+// Two users: spamat_fwd_sparse (256 threads, 256 slots, 8 tiles: six workgroups per CU, the sparse regime's roofline
+// numbers) and, round 3, the band kernel's own workgroup on the rows that kernel hands over (512 threads, 512 slots,
+// NT + 1 tiles): rows of 257-512 active pixels per side (densities 0.25-0.5 at stage 3) no longer fall onto the band
+// kernel's compact path, which stages the whole right row and fetches the left features per 16-pixel chunk.
+template <int NT, int MODE, int KQ, int PPT, int NTHR, int CAP, int NTCMAX>
+__device__ __forceinline__ int sparse_row_body(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int seg_w, int dense_pct, int mbits) {
+    int H, int W, int D, int row, int dense_pct, int mbits) {
     // at most 8 cost tiles per span (32 accumulator registers: six workgroups per CU); a row whose
     // disparity windows hold more than 8*16-15 active right pixels even for 16-pixel spans goes to
     // spamat_fwd_mfma like the dense ones
-    constexpr int CQ = 4 * KQ, NTC = NT + 1 < 8 ? NT + 1 : 8;
+    constexpr int CQ = 4 * KQ, NTC = NT + 1 < NTCMAX ? NT + 1 : NTCMAX;
+    constexpr int SP_NWAVE_ = NTHR / 64, SP_FP_ = CAP + 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // words: XR [CAP+16] | RK [(NPX+4) x u16] | RKL [(NPX+4) x u16] | XL [CAP] | WT [16] | RF [CQ][FP] | LF [CQ][FP]
-    constexpr int NPX = SP_THREADS * PPT, RKW = NPX / 2 + 2;               // RK / RKL: NPX + 4 u16
-    constexpr int offXR = 0, offRK = SP_CAP + 16, offRKL = offRK + RKW, offXL = offRKL + RKW,
-                  offWT = offXL + SP_CAP, offRF = offWT + 16, offLF = offRF + CQ * SP_FP;
+    constexpr int NPX = NTHR * PPT, RKW = NPX / 2 + 2;               // RK / RKL: NPX + 4 u16
+    constexpr int offXR = 0, offRK = CAP + 16, offRKL = offRK + RKW, offXL = offRKL + RKW,
+                  offWT = offXL + CAP, offRF = offWT + 32, offLF = offRF + CQ * SP_FP_;
     int *XR = reinterpret_cast<int *>(smem) + offXR;
     unsigned short *RK = reinterpret_cast<unsigned short *>(smem + offRK);
     unsigned short *RKL = reinterpret_cast<unsigned short *>(smem + offRKL);
@@ -889,7 +919,7 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     float *RF = smem + offRF, *LF = smem + offLF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = blockIdx.x, b = row / H, y = row - b * H;
+    const int b = row / H, y = row - b * H;
     const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
     const float *lrow = ref + ((size_t)b * C * H + y) * W;
     const float *rrow = tar + ((size_t)b * C * H + y) * W;
@@ -917,22 +947,20 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     }
     const int cr = __popc(fr), cl = __popc(fl);
     const int ir = wave_incl_scan(cr, lane), il = wave_incl_scan(cl, lane);
-    if (lane == 63) { WT[wave] = ir; WT[4 + wave] = il; }
+    if (lane == 63) { WT[wave] = ir; WT[8 + wave] = il; }
     __syncthreads();
     int nR = 0, nL = 0, baseR = 0, baseL = 0;
 #pragma unroll
-    for (int w = 0; w < SP_NWAVE; ++w) {
-        if (w < wave) { baseR += WT[w]; baseL += WT[4 + w]; }
+    for (int w = 0; w < SP_NWAVE_; ++w) {
+        if (w < wave) { baseR += WT[w]; baseL += WT[8 + w]; }
         nR += WT[w];
-        nL += WT[4 + w];
+        nL += WT[8 + w];
     }
-    auto hand_over = [&]() {                           // left to spamat_fwd_mfma (marker launch)
-        for (int x = tid * seg_w; x < W; x += SP_THREADS * seg_w) sum_sim[rowpix + x] = -1.0f;
-    };
-    if (nL > SP_CAP || nR > SP_CAP || (long)nL * nR * 100 >= (long)W * W * dense_pct) {
-        hand_over();
-        return;
-    }
+    // not sparse enough for this body: nothing has been written, the caller decides (the stand-alone kernel marks the
+    // row for the band kernel, the band kernel goes on with its own paths).
+    // (2: few enough active pixels for the 512-slot body of the band kernel; 0: a dense row)
+    if ((long)nL * nR * 100 >= (long)W * W * dense_pct) return 0;
+    if (nL > CAP || nR > CAP) return (nL <= MID_CAP && nR <= MID_CAP) ? 2 : 0;
     {
         int er = baseR + ir - cr, el = baseL + il - cl; // exclusive counts at p4
 #pragma unroll
@@ -961,29 +989,26 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     while (S > 16 && (long)S * nL > 24L * W) S >>= 1;
     for (;;) {
         int bad = 0;
-        for (int g = tid; g * S < W; g += SP_THREADS) {
+        for (int g = tid; g * S < W; g += NTHR) {
             const int jlo = max(0, g * S - (D - 1)), jhi = min(W - 1, g * S + S - 1);
             if ((int)RK[jhi + 1] - (int)RK[jlo] > 16 * NTC - 15) bad = 1;
         }
         if (!__syncthreads_or(bad)) break;
-        if (S == 16) {                                  // nothing written yet: hand the row over
-            hand_over();
-            return;
-        }
+        if (S == 16) return 2;                          // nothing written yet; more tiles per span may do
         S >>= 1;
     }
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {
-        RF[c * SP_FP + tid] = rf[c];                    // slots >= nR hold zeros
-        LF[c * SP_FP + tid] = lf[c];
-        if (tid < 16) RF[c * SP_FP + SP_CAP + tid] = 0.f;
+        RF[c * SP_FP_ + tid] = rf[c];                    // slots >= nR hold zeros
+        LF[c * SP_FP_ + tid] = lf[c];
+        if (tid < 16) RF[c * SP_FP_ + CAP + tid] = 0.f;
     }
     __syncthreads();
 
     // ---- 3. matching
     const int j = lane & 15, q = lane >> 4;
     const int ngroups = (W + S - 1) / S;
-    for (int g = wave; g < ngroups; g += SP_NWAVE) {
+    for (int g = wave; g < ngroups; g += SP_NWAVE_) {
         const int gx = g * S;
         const int e0 = RKL[gx], e1 = RKL[min(gx + S, W)];
         if (e1 == e0) continue;
@@ -998,16 +1023,16 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
             const size_t pix = rowpix + xl;
             float bcur[KQ];
 #pragma unroll
-            for (int s = 0; s < KQ; ++s) bcur[s] = act ? LF[(4 * s + q) * SP_FP + el] : 0.f;
+            for (int s = 0; s < KQ; ++s) bcur[s] = act ? LF[(4 * s + q) * SP_FP_ + el] : 0.f;
             f32x4 acc[NTC];
-            const float *ap = RF + q * SP_FP + 16 * t0 + j;
+            const float *ap = RF + q * SP_FP_ + 16 * t0 + j;
 #pragma unroll
             for (int m = 0; m < NTC; ++m) {
                 if (m < ntile) {
                     f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < KQ; ++s)
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * SP_FP + 16 * m], bcur[s], a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * SP_FP_ + 16 * m], bcur[s], a4, 0, 0, 0);
                     acc[m] = a4;
                 }
             }
@@ -1019,9 +1044,9 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
             // into bcur above and no other wave reads them); the row is written once at the end
             if (act && q == 0) {
                 if (MODE != MODE_VAR) LF[el] = mu;
-                if (MODE != MODE_MAT) LF[SP_FP + el] = var;
-                LF[2 * SP_FP + el] = Ssum;
-                LF[3 * SP_FP + el] = mx;
+                if (MODE != MODE_MAT) LF[SP_FP_ + el] = var;
+                LF[2 * SP_FP_ + el] = Ssum;
+                LF[3 * SP_FP_ + el] = mx;
             }
         }
     }
@@ -1041,7 +1066,7 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
             for (int k = 0; k < 4; ++k) {
                 const bool on = fl & (1 << (u + k));
 #pragma unroll
-                for (int o = 0; o < 4; ++o) r[o][k] = on ? LF[o * SP_FP + slot] : 0.f;
+                for (int o = 0; o < 4; ++o) r[o][k] = on ? LF[o * SP_FP_ + slot] : 0.f;
                 slot += on;
             }
             const size_t pix = rowpix + p4 + u;
@@ -1062,6 +1087,27 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
                 }
             }
         }
+    }
+    return 1;
+}
+
+// PPT = pixels per thread of the mask scan: 4 (W <= 1024) or 8 (W <= 2048).  seg_w = pixels per
+// segment of the marker launch (it splits rows wider than 1024 pixels): one marker per segment.
+template <int NT, int MODE, int KQ, int PPT>
+__global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_sparse(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
+    float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
+    int H, int W, int D, int seg_w, int dense_pct, int mbits) {
+    const int row = blockIdx.x;
+    const int rc = sparse_row_body<NT, MODE, KQ, PPT, SP_THREADS, SP_CAP, 8>(ref, tar, rmask, tmask, disparity, out, var_out,
+                                                                            sum_sim, max_cost, C, H, W, D, row, dense_pct, mbits);
+    if (rc != 1) {
+        // left to spamat_fwd_mfma (marker launch): a negative value at the first pixel of every segment of the row (a
+        // real sum_similarities is never negative); -2: <= 512 active pixels per side, worth the 512-slot body there
+        const size_t rowpix = (size_t)row * W;
+        const float mark = rc == 2 ? -2.0f : -1.0f;
+        for (int x = threadIdx.x * seg_w; x < W; x += SP_THREADS * seg_w) sum_sim[rowpix + x] = mark;
     }
 }
 
@@ -1105,11 +1151,21 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     // (C = 24, stage 2: rows are short and in practice 40-100 % dense -- there the sparse-row pre-launch costs 6 us
     // of a 57 us pass and only wins below ~20 % density; DECNET_SPAMAT_SPARSE=2 switches it on for C <= 24 too)
     static const int sparse_c24 = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 2; }();
-    const int marker = allow_compact && !sparse_off && (KQ == 2 || (KQ == 6 && sparse_c24)) && W <= 2048;
+    int marker = allow_compact && !sparse_off && (KQ == 2 || (KQ == 6 && sparse_c24)) && W <= 2048;
+    // rows of 257-512 active pixels per side: the sparse-row algorithm inside the band kernel's workgroup (whole rows
+    // per workgroup only; DECNET_SPAMAT_MID=0 switches it off)
+    static const int mid_off = [] { const char *e = getenv("DECNET_SPAMAT_MID"); return e && atoi(e) == 0; }();
+    size_t lds_launch = lds;
+    if (KQ == 2 && marker && segs == 1 && !mid_off) {
+        const size_t need = 4 * sparse_row_words(KQ, 4, THREADS, MID_CAP);
+        if (need <= budget2 + 8192) {
+            marker = 2;
+            if (need > lds_launch) lds_launch = need;
+        }
+    }
     if constexpr (KQ > 0 && KQ <= 6) if (marker) {
         const int ppt = W <= 1024 ? 4 : 8;
-        const size_t slds = 4 * (size_t)(SP_CAP + 16 + 2 * (SP_THREADS * ppt / 2 + 2) + SP_CAP + 16 +
-                                         2 * 4 * KQ * SP_FP);
+        const size_t slds = 4 * sparse_row_words(KQ, ppt, SP_THREADS, SP_CAP);
 #define LAUNCHS(M, P)                                                                              \
     do {                                                                                           \
         if (slds > 64 * 1024) {                                                                    \
@@ -1136,12 +1192,12 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     }
 #define LAUNCH1(M, DD)                                                                             \
     do {                                                                                           \
-        if (lds > 64 * 1024) {                                                                     \
+        if (lds_launch > 64 * 1024) {                                                              \
             hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_mfma<NT, M, KQ, DD>,       \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch); \
             if (e != hipSuccess) return (int)e;                                                    \
         }                                                                                          \
-        hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ, DD>), grid, block, lds, stream, ref, tar, rmask, \
+        hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ, DD>), grid, block, lds_launch, stream, ref, tar, rmask, \
                            tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT, \
                            allow_compact, marker, compact_pct, mbits);                             \
     } while (0)

@@ -25,7 +25,42 @@ __global__ __launch_bounds__(256) void unfold3_cat(const float *__restrict__ fea
         o[(size_t)(1 + c * 9 + i * 3 + 2) * cp] = v2;
     }
 }
+// The stride-3 convolutions of FeatExtNetChannelPlus (Conv2d k 3, stride 3, padding 1: submodule.py:270-300) as a
+// space-to-depth gather in front of a 1 x 1 convolution on the matrix cores (csrc/conv2d_mfma.hip):
+//     out[b, c*9 + ky*3 + kx, yo, xo] = x[b, c, 3 yo - 1 + ky, 3 xo - 1 + kx]   (0 outside the image)
+// -- every input pixel feeds exactly one output pixel, so this is a permutation with a zero border; the channel order
+// is the row-major flattening of the weight [Cout, Cin, 3, 3].
+__global__ __launch_bounds__(256) void s2d3_pad1(const float *__restrict__ x, float *__restrict__ out, int C, int H, int W,
+                                                 int Ho, int Wo) {
+    const int xo = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y;
+    const int b = blockIdx.z / C, c = blockIdx.z - b * C;
+    if (xo >= Wo) return;
+    const size_t cp = (size_t)Ho * Wo;
+    float *o = out + ((size_t)b * 9 * C + 9 * c) * cp + (size_t)yo * Wo + xo;
+    const float *f = x + ((size_t)b * C + c) * H * (size_t)W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yi = 3 * yo - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xi = 3 * xo - 1 + kx;
+            float v = 0.f;
+            if (yi >= 0 && yi < H && xi >= 0 && xi < W) v = f[(size_t)yi * W + xi];
+            o[(size_t)(ky * 3 + kx) * cp] = v;
+        }
+    }
+}
 }  // namespace
+
+extern "C" int decnet_s2d3_pad1(const float *x, float *out, int B, int C, int H, int W, void *stream) {
+    if (!x || !out) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || C < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
+    const int Ho = (H - 1) / 3 + 1, Wo = (W - 1) / 3 + 1;            // floor((H + 2 - 3) / 3) + 1
+    if (Ho > 65535 || (long)B * C > 65535) return DECNET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(s2d3_pad1, dim3((unsigned)ceil_div(Wo, 256), (unsigned)Ho, (unsigned)(B * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, C, H, W, Ho, Wo);
+    return decnet_launch_status();
+}
 
 extern "C" int decnet_unfold3_cat(const float *fea, const float *disp, float *out, int B, int C, int h, int w,
                                   void *stream) {

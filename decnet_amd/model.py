@@ -56,12 +56,23 @@ class Unit(nn.Module):
         c = self.conv
         # many channels: the bf16x3 matrix-core kernel (csrc/conv2d_mfma.hip) where the image gives it enough
         # workgroups (>= 4096 pixels, e.g. the 60 x 108 level; at 20 x 36 the library's kernels win)
-        if (isinstance(c, nn.Conv2d) and (c.out_channels >= 24 or c.in_channels >= 48) and c.in_channels >= 16 and
-                c.kernel_size in ((1, 1), (3, 3)) and
+        # (round 3: also 9..23 outputs from >= 16 inputs.  The 20 x 36 level stays on the library: measured with
+        # DECNET_MFMA_MIN_PIXELS=512, 649 -> 81 takes 0.265 ms here against 0.107 ms, the 864 / 432 -> 216 1 x 1 layers
+        # 0.131 / 0.081 against 0.053 / 0.042 -- 144 workgroups of a K = 5841 reduction each do not fill 256 CUs)
+        if (isinstance(c, nn.Conv2d) and
+                (c.out_channels >= int(os.environ.get("DECNET_MFMA_MIN_COUT", "9")) or c.in_channels >= 48) and
+                c.in_channels >= 16 and c.kernel_size in ((1, 1), (3, 3)) and
                 c.stride == (1, 1) and c.dilation[0] == c.dilation[1] and c.groups == 1 and c.padding_mode == "zeros" and
-                c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and x.shape[-1] * x.shape[-2] >= 4096 and
+                c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and
+                x.shape[-1] * x.shape[-2] >= int(os.environ.get("DECNET_MFMA_MIN_PIXELS", "4096")) and
                 c.dilation[0] <= 4 and os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma"
+        # Conv2d k 3, stride 3, padding 1 with more than 24 outputs: space-to-depth + the same kernel as a 1 x 1 convolution
+        if (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (1, 1) and
+                c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros" and c.out_channels > 24 and
+                c.in_channels >= 8 and x.shape[-1] * x.shape[-2] >= 4608 and
+                os.environ.get("DECNET_CONV2D_MFMA", "1") == "1" and os.environ.get("DECNET_MFMA_S3", "1") == "1"):
+            return "mfma_s3"
         # transposed convolution k = 3, stride 3 with more than 8 output channels: the same kernel, as a 1 x 1 convolution
         # to 9 Cout channels with a pixel-shuffle store
         if (isinstance(c, nn.ConvTranspose2d) and (c.out_channels > 8 or c.in_channels >= 64) and c.in_channels >= 16 and
@@ -145,7 +156,12 @@ class Unit(nn.Module):
                     shift = c.bias.float() if c.bias is not None else torch.zeros(co, device=c.weight.device)
                 w = c.weight.detach().float().contiguous()
                 st = torch.cuda.current_stream(w.device).cuda_stream
-                if isinstance(c, nn.ConvTranspose2d):
+                if isinstance(c, nn.Conv2d) and c.stride == (3, 3):      # stride-3: [Cout, Cin, 3, 3] read as [Cout, 9 Cin]
+                    wp = torch.empty(L.decnet_conv2d_mfma_packed_bytes(9 * ci, co, 1), dtype=torch.uint8, device=w.device)
+                    with torch.cuda.device(w.device):
+                        _lib.check(L.decnet_conv2d_mfma_pack_weight(w.data_ptr(), wp.data_ptr(), 9 * ci, co, 1, st),
+                                   "decnet_conv2d_mfma_pack_weight")
+                elif isinstance(c, nn.ConvTranspose2d):
                     wp = torch.empty(L.decnet_deconv2d_mfma_packed_bytes(ci, co), dtype=torch.uint8, device=w.device)
                     with torch.cuda.device(w.device):
                         _lib.check(L.decnet_deconv2d_mfma_pack_weight(w.data_ptr(), wp.data_ptr(), ci, co, st),
@@ -179,6 +195,29 @@ class Unit(nn.Module):
         _lib.check(rc, "decnet_conv2d_mfma_cat_bn_act")
         return y
 
+    def _forward_mfma_s3(self, x):
+        """Conv2d k 3, stride 3, padding 1: decnet_s2d3_pad1 + the matrix-core kernel as a 1 x 1 convolution."""
+        import ctypes
+        from . import _lib
+        from .ops import _stream
+        wp, scale, shift = self._folded_mfma()
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        c = self.conv
+        Ho, Wo = (H - 1) // 3 + 1, (W - 1) // 3 + 1
+        t = torch.empty((B, 9 * Cin, Ho, Wo), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, c.out_channels, Ho, Wo), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            _lib.check(L.decnet_s2d3_pad1(x.data_ptr(), t.data_ptr(), B, Cin, H, W, _stream(x)), "decnet_s2d3_pad1")
+            ptrs = (ctypes.c_void_p * 1)(t.data_ptr())
+            cins = (ctypes.c_int * 1)(9 * Cin)
+            rc = L.decnet_conv2d_mfma_cat_bn_act(ptrs, cins, 1, wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                 y.data_ptr(), B, c.out_channels, Ho, Wo, 1, 1, 1 if self.relu else 0,
+                                                 _stream(y))
+        _lib.check(rc, "decnet_conv2d_mfma_cat_bn_act")
+        return y
+
     def _forward_mfma_deconv(self, x):
         from . import _lib
         from .ops import _stream
@@ -201,6 +240,8 @@ class Unit(nn.Module):
             return self._forward_mfma(x)
         if kind == "mfma_deconv":
             return self._forward_mfma_deconv(x)
+        if kind == "mfma_s3":
+            return self._forward_mfma_s3(x)
         from . import _lib
         from .ops import _stream
         w, scale, shift = self._folded(neg_last)
@@ -457,7 +498,7 @@ class FeatExtNetChannelPlus(nn.Module):
         f1 = self.conv1(f0)
         f2 = self.conv2(f1)
         f3a = self.conv3_1(f2)
-        f3 = self.addition_fusion(torch.cat((self.conv3_2(f3a), self.addition_ctx_collection(f3a)), 1))
+        f3 = self.addition_fusion((self.conv3_2(f3a), self.addition_ctx_collection(f3a)))    # (the concatenation is the unit's)
         s1, _ = self.deconv3(self.addition_trans2(f2), f3)
         s2, _ = self.deconv2(self.addition_trans1(f1), s1)
         s3, _ = self.deconv1(self.addition_trans0(f0), s2)

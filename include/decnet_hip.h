@@ -280,6 +280,11 @@ int decnet_detail_mask(const float *cur3, const float *pre3, const float *w3x3, 
                        void *stream);
 /* Head of DynamicUpsampling.forward (submodule.py:578-580): out = cat(disp, unfold(fea, 3, stride 3)):
  * fea [B,C,3h,3w], disp [B,h,w] -> out [B,9C+1,h,w], out[b,0] = disp, out[b,1+9c+3i+j,y,x] = fea[b,c,3y+i,3x+j]. */
+/* Space-to-depth in front of the stride-3 convolutions of FeatExtNetChannelPlus (Conv2d k 3, stride 3, padding 1,
+ * submodule.py:270-300): x [B,C,H,W] -> out [B,9C,Ho,Wo], Ho = (H-1)/3+1, Wo = (W-1)/3+1,
+ * out[b,c*9+ky*3+kx,yo,xo] = x[b,c,3yo-1+ky,3xo-1+kx] (0 outside); the convolution is then the 1 x 1 convolution with the
+ * weight [Cout,Cin,3,3] read as [Cout,9 Cin] (decnet_conv2d_mfma_cat_bn_act, k = 1). */
+int decnet_s2d3_pad1(const float *x, float *out, int B, int C, int H, int W, void *stream);
 int decnet_unfold3_cat(const float *fea, const float *disp, float *out, int B, int C, int h, int w,
                        void *stream);
 /* y[b,c,:,:] = act(y[b,c,:,:] + shift[c]) in place, y [B,C,H,W]: the folded-BatchNorm bias and the ReLU

@@ -132,6 +132,42 @@ def test_mfma_conv_is_what_the_many_channel_units_run(dev):
         assert u._hip_kind(x[:, :, :20, :36]) is None                             # small images stay on the library
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(24, 72, (2, 180, 324)), (72, 216, (2, 60, 108)), (8, 40, (1, 100, 203))])
+def test_stride3_conv_on_the_matrix_cores_vs_torch_cpu(dev, cin, cout, shape):
+    """Conv2d k 3, stride 3, padding 1 with more than 24 outputs (FeatExtNetChannelPlus conv2[0], conv3_1,
+    submodule.py:270-300): decnet_s2d3_pad1 + the matrix-core kernel as a 1 x 1 convolution over 9 Cin channels."""
+    from decnet_amd.model import Unit
+    torch.manual_seed(cin + cout)
+    u = Unit(cin, cout, 3, stride=3, pad=1).eval()
+    u.bn.weight.data.uniform_(0.5, 1.5); u.bn.bias.data.normal_(0, 0.2)
+    u.bn.running_mean.data.normal_(0, 0.2); u.bn.running_var.data.uniform_(0.5, 1.5)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(shape[0], cin, shape[1], shape[2], generator=g)
+    with torch.no_grad():
+        ref = u.double()(x.double()).float()
+        ud = u.float().to(dev)
+        assert ud._hip_kind(x.to(dev)) == "mfma_s3"
+        got = ud(x.to(dev)).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_few_outputs_from_many_inputs_run_on_the_matrix_cores(dev):
+    """Round 3: <= 8 outputs from >= 48 inputs (GenerateSparseMask / SoftAttention at 1/9 resolution) and 9..23 outputs
+    from >= 16 inputs (Refinement 24 -> 12 at 1/3 resolution) go to csrc/conv2d_mfma.hip; vs torch CPU float64."""
+    g = torch.Generator().manual_seed(4)
+    for cins, cout, shape in (((72,), 8, (2, 60, 108)), ((72, 1, 1, 1, 1), 8, (2, 60, 108)), ((24,), 12, (1, 180, 324))):
+        u = _unit(sum(cins), cout, 3, seed=sum(cins) + cout)
+        xs = [torch.randn(shape[0], c, shape[1], shape[2], generator=g) for c in cins]
+        with torch.no_grad():
+            ref = u.double()(torch.cat(xs, 1).double()).float()
+            ud = u.float().to(dev)
+            xd = tuple(t.to(dev) for t in xs) if len(xs) > 1 else xs[0].to(dev)
+            assert ud._hip_kind(xd) == "mfma"
+            got = ud(xd).cpu()
+        assert float((got - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,relu,bn", [(24, 8, True, True), (9, 8, True, False), (24, 3, False, True)])
 def test_deconv_unit_vs_torch_cpu(dev, cin, cout, relu, bn):
     u = _unit(cin, cout, 3, relu=relu, bn=bn, transposed=True, seed=cin + cout)

@@ -166,10 +166,6 @@ def test_inputdata_pair_matches_reference_graph(ds_name, name, variant):
     print("         gate vs the reference's float32 run: %.2e px (%s)" % (gate, "plain 1e-3" if gate == 1e-3 else
                                                                             "1e-3 + 2 x reference noise"))
     assert err[clean].mean() < gate
-    if variant == "fill" and r64m < 4e-4:
-        # every pixel, flip neighbourhoods included (a flipped bit moves its surroundings by whole pixels; the reference's
-        # own float32 run has such pixels against its float64 run too: that part is allowed twice over)
-        assert err.mean() < 2e-3 + 2 * e_ref64.mean(), "all-pixel mean (flip neighbourhoods included)"
     # the written image: x256 uint16 (demo.py:191-197); one count = 1/256 px
     dp = np.abs(png.astype(np.int64)[s3] - d["pred_png_s3"].astype(np.int64))
     oh, ow = png.shape
