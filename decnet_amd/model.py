@@ -14,6 +14,7 @@ not runnable as shipped.
 """
 import math
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -343,6 +344,20 @@ class Unit(nn.Module):
         if self.bn is not None:
             x = self.bn(x)
         return F.relu(x) if self.relu else x
+
+
+_SIDE = threading.local()
+
+
+def _side_stream(device):
+    """One extra HIP stream per (host thread, device): DataParallel drives replicas from worker threads."""
+    d = getattr(_SIDE, "streams", None)
+    if d is None:
+        d = _SIDE.streams = {}
+    key = torch.device(device).index
+    if key not in d:
+        d[key] = torch.cuda.Stream(device=device)
+    return d[key]
 
 
 def _seq(*units):
@@ -785,22 +800,39 @@ class SparseDenseNetRefinementMask(nn.Module):
             else:
                 lmask, rmask = left_mask_list[stage - 1], right_mask_list[stage - 1]
                 lbits = rbits = None
-            dense = self.dynamic_upsampling[stage - 1](pred, L)           # reference :178
             # SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch; the masks as the bit-packed
-            # copies the mask kernel wrote where there are any (the float planes stay what SoftAttention reads)
-            res = None
-            if (lbits is not None and rbits is not None and cur_max_disp <= 272 and
-                    os.environ.get("DECNET_SPAMAT_BITS", "1") == "1"):
-                try:
-                    res = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, cur_max_disp)
-                except DecnetHipError as e:             # shapes only the float-mask entry's fallback kernels cover
-                    if e.code != UNSUPPORTED:
-                        raise
-            if res is not None:
-                sparse, var, _, _ = res
+            # copies the mask kernel wrote where there are any (the float planes stay what SoftAttention reads).  It
+            # depends on the features and the masks only, DynamicUpsampling (reference :178) on the coarser prediction and
+            # the features: on the GPU the two run side by side on two HIP streams (fp32-issue-bound cost-volume pass beside
+            # bf16 matrix-core convolutions), joined before the attention.
+            def sparse_pass(out=None):
+                res = None
+                if (lbits is not None and rbits is not None and cur_max_disp <= 272 and
+                        os.environ.get("DECNET_SPAMAT_BITS", "1") == "1"):
+                    try:
+                        res = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, cur_max_disp, out=out)
+                    except DecnetHipError as e:         # shapes only the float-mask entry's fallback kernels cover
+                        if e.code != UNSUPPORTED:
+                            raise
+                if res is None:
+                    res = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(), rmask.contiguous(),
+                                            cur_max_disp, out=out)
+                return res
+            if L.is_cuda and os.environ.get("DECNET_OVERLAP", "1") == "1":
+                cur = torch.cuda.current_stream(L.device)
+                side = _side_stream(L.device)
+                outs = tuple(torch.empty(L.shape[0], L.shape[2], L.shape[3], dtype=torch.float32, device=L.device)
+                             for _ in range(4))            # allocated on (and later freed to) the main stream
+                Lc, Rc = L.contiguous(), R.contiguous()     # (views of the batched features: already contiguous)
+                side.wait_stream(cur)                       # features and masks are ready
+                with torch.cuda.stream(side):
+                    sparse, var, _, _ = sparse_pass(outs)
+                dense = self.dynamic_upsampling[stage - 1](pred, L)
+                cur.wait_stream(side)
+                del Lc, Rc
             else:
-                sparse, var, _, _ = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(),
-                                                      rmask.contiguous(), cur_max_disp)
+                dense = self.dynamic_upsampling[stage - 1](pred, L)       # reference :178
+                sparse, var, _, _ = sparse_pass()
             fused = self.soft_attention[stage - 1].fuse(L, dense, sparse, lmask, var)     # reference :195-202
             pred, _ = self.refinement[stage - 1](L, R, fused)             # reference :207
         return [pred]

@@ -17,13 +17,17 @@ def spamat_spy(callback):
     import decnet_amd.model as M
     orig_f, orig_b = M.spamatvar_forward, M.spamatvar_forward_bits
 
-    def spy_f(L, R, lm, rm, D):
-        o = orig_f(L, R, lm, rm, D)
+    # (the graph runs this call on a side stream beside DynamicUpsampling: the callback reads the outputs, so it
+    # synchronises that stream first)
+    def spy_f(L, R, lm, rm, D, out=None):
+        o = orig_f(L, R, lm, rm, D, out=out)
+        torch.cuda.current_stream(L.device).synchronize()
         callback(L, R, lm, rm, D, o)
         return o
 
-    def spy_b(L, R, lb, rb, D):
-        o = orig_b(L, R, lb, rb, D)
+    def spy_b(L, R, lb, rb, D, out=None):
+        o = orig_b(L, R, lb, rb, D, out=out)
+        torch.cuda.current_stream(L.device).synchronize()
         W = L.shape[-1]
         callback(L, R, unpack_mask_bits(lb, W), unpack_mask_bits(rb, W), D, o)
         return o
