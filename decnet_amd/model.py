@@ -768,71 +768,87 @@ class SparseDenseNetRefinementMask(nn.Module):
         else:
             lf = self.feature_extractor(left)
             rf = self.feature_extractor(right)
-        pred = None
-        for stage in range(self.num_stage):
+        nstage = self.num_stage
+
+        def max_disp_of(stage):
+            return self.max_disp // self.down_scale ** (nstage - stage - 1)
+
+        def masks_of(stage):
+            """reference :148-170 -> (lmask, rmask, lbits, rbits)"""
             L, R = lf["stage%d" % stage], rf["stage%d" % stage]
-            cur_max_disp = self.max_disp // self.down_scale ** (self.num_stage - stage - 1)
+            if not self.use_detail:
+                return left_mask_list[stage - 1], right_mask_list[stage - 1], None, None
+            gen = self.detail_detection[stage - 1]
+            # both views as one batch of 2 B samples where the levels are launch-bound (1/9, 1/3 resolution); at full
+            # resolution a [16,8,540,972] tensor is 268 MB -- more than the 256 MiB Infinity Cache that keeps a
+            # view's 134 MB intermediates on chip between producer and consumer (measured: 656 vs 608 us)
+            if f2 is not None and 2 * L.numel() * 4 <= (96 << 20):
+                m2, b2 = gen.mask(f2["stage%d" % stage], f2["stage%d" % (stage - 1)], self.thold, want_bits=True)
+                nb = L.shape[0]
+                return m2[:nb], m2[nb:], (b2[:nb] if b2 is not None else None), (b2[nb:] if b2 is not None else None)
+            lmask, lbits = gen.mask(L, lf["stage%d" % (stage - 1)], self.thold, want_bits=True)
+            rmask, rbits = gen.mask(R, rf["stage%d" % (stage - 1)], self.thold, want_bits=True)
+            return lmask, rmask, lbits, rbits
+
+        def sparse_of(stage, masks, out=None):
+            """SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch; the masks as the bit-packed
+            copies the mask kernel wrote where there are any (the float planes stay what SoftAttention reads)."""
+            L, R = lf["stage%d" % stage], rf["stage%d" % stage]
+            lmask, rmask, lbits, rbits = masks
+            D = max_disp_of(stage)
+            res = None
+            if (lbits is not None and rbits is not None and D <= 272 and os.environ.get("DECNET_SPAMAT_BITS", "1") == "1"):
+                try:
+                    res = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, D, out=out)
+                except DecnetHipError as e:             # shapes only the float-mask entry's fallback kernels cover
+                    if e.code != UNSUPPORTED:
+                        raise
+            if res is None:
+                res = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(), rmask.contiguous(), D, out=out)
+            return res[0], res[1]
+
+        # The masks and the SpaMat / SpaVar pass of EVERY level depend on the feature maps only -- not on the coarser
+        # level's prediction (reference :148-192).  On the GPU they run ahead on a second HIP stream, beside the stage-0
+        # Conv3d stack and the DynamicUpsampling convolutions (fp32-issue- and HBM-bound kernels beside bf16 matrix-core
+        # GEMMs); the main stream picks a level's results up behind an event.  DECNET_OVERLAP=0: everything in order.
+        stages = [st for st in range(1, nstage) if st < self.skip_stage_id]
+        ahead = {}
+        overlap = left.is_cuda and os.environ.get("DECNET_OVERLAP", "1") == "1" and stages
+        if overlap:
+            cur = torch.cuda.current_stream(left.device)
+            side = _side_stream(left.device)
+            side.wait_stream(cur)                          # the feature maps are ready
+            with torch.cuda.stream(side):
+                for st in stages:
+                    masks = masks_of(st)
+                    sp = sparse_of(st, masks)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    for t in masks + sp:                    # allocated on the side stream, consumed on the main one
+                        if t is not None:
+                            t.record_stream(cur)
+                    ahead[st] = (masks, sp, ev)
+
+        pred = None
+        for stage in range(nstage):
+            L, R = lf["stage%d" % stage], rf["stage%d" % stage]
             if stage == 0:
                 # get_disp_samples -> GetCostVolume -> CostRegNetNoDown -> disparity_regression
                 # (reference :127-137) as one channels-last pipeline on the matrix cores
-                pred = self.cost_regularizer.stage0(L, R, cur_max_disp)
-                pre_L, pre_R = L, R
+                pred = self.cost_regularizer.stage0(L, R, max_disp_of(0))
                 continue
             if stage >= self.skip_stage_id:                               # reference :143-144
                 pred = F.interpolate(pred.unsqueeze(1) * self.down_scale, L.shape[-2:],
                                      mode="bicubic").squeeze(1)
                 continue
-            if self.use_detail:                                           # reference :148-170
-                gen = self.detail_detection[stage - 1]
-                # both views as one batch of 2 B samples where the levels are launch-bound (1/9, 1/3 resolution); at full
-                # resolution a [16,8,540,972] tensor is 268 MB -- more than the 256 MiB Infinity Cache that keeps a
-                # view's 134 MB intermediates on chip between producer and consumer (measured: 656 vs 608 us)
-                if f2 is not None and 2 * L.numel() * 4 <= (96 << 20):
-                    cur2, pre2 = f2["stage%d" % stage], f2["stage%d" % (stage - 1)]
-                    m2, b2 = gen.mask(cur2, pre2, self.thold, want_bits=True)
-                    nb = L.shape[0]
-                    lmask, rmask = m2[:nb], m2[nb:]
-                    lbits, rbits = (b2[:nb], b2[nb:]) if b2 is not None else (None, None)
-                else:
-                    lmask, lbits = gen.mask(L, pre_L, self.thold, want_bits=True)
-                    rmask, rbits = gen.mask(R, pre_R, self.thold, want_bits=True)
-                pre_L, pre_R = L, R
+            dense = self.dynamic_upsampling[stage - 1](pred, L)           # reference :178
+            if overlap:
+                masks, (sparse, var), ev = ahead.pop(stage)
+                cur.wait_event(ev)
             else:
-                lmask, rmask = left_mask_list[stage - 1], right_mask_list[stage - 1]
-                lbits = rbits = None
-            # SpaMat + (no_grad) SpaVar around its output, reference :183-192, one launch; the masks as the bit-packed
-            # copies the mask kernel wrote where there are any (the float planes stay what SoftAttention reads).  It
-            # depends on the features and the masks only, DynamicUpsampling (reference :178) on the coarser prediction and
-            # the features: on the GPU the two run side by side on two HIP streams (fp32-issue-bound cost-volume pass beside
-            # bf16 matrix-core convolutions), joined before the attention.
-            def sparse_pass(out=None):
-                res = None
-                if (lbits is not None and rbits is not None and cur_max_disp <= 272 and
-                        os.environ.get("DECNET_SPAMAT_BITS", "1") == "1"):
-                    try:
-                        res = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, cur_max_disp, out=out)
-                    except DecnetHipError as e:         # shapes only the float-mask entry's fallback kernels cover
-                        if e.code != UNSUPPORTED:
-                            raise
-                if res is None:
-                    res = spamatvar_forward(L.contiguous(), R.contiguous(), lmask.contiguous(), rmask.contiguous(),
-                                            cur_max_disp, out=out)
-                return res
-            if L.is_cuda and os.environ.get("DECNET_OVERLAP", "1") == "1":
-                cur = torch.cuda.current_stream(L.device)
-                side = _side_stream(L.device)
-                outs = tuple(torch.empty(L.shape[0], L.shape[2], L.shape[3], dtype=torch.float32, device=L.device)
-                             for _ in range(4))            # allocated on (and later freed to) the main stream
-                Lc, Rc = L.contiguous(), R.contiguous()     # (views of the batched features: already contiguous)
-                side.wait_stream(cur)                       # features and masks are ready
-                with torch.cuda.stream(side):
-                    sparse, var, _, _ = sparse_pass(outs)
-                dense = self.dynamic_upsampling[stage - 1](pred, L)
-                cur.wait_stream(side)
-                del Lc, Rc
-            else:
-                dense = self.dynamic_upsampling[stage - 1](pred, L)       # reference :178
-                sparse, var, _, _ = sparse_pass()
+                masks = masks_of(stage)
+                sparse, var = sparse_of(stage, masks)
+            lmask = masks[0]
             fused = self.soft_attention[stage - 1].fuse(L, dense, sparse, lmask, var)     # reference :195-202
             pred, _ = self.refinement[stage - 1](L, R, fused)             # reference :207
         return [pred]
