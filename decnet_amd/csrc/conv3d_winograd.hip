@@ -470,6 +470,199 @@ __global__ __launch_bounds__(256) void wino_output_transform(
         wino_output_body<TD, TH, TW, KS, KS - 1>(M, scale, shift, residual, y, g, Co, relu, t_lo, nt, y_bytes, cg, tl, (int)(idx & 15));
 }
 
+// ------------------------------ output transform of layer i + input transform of layer i + 1 ----
+// Between two Winograd layers the activation y never has to reach HBM: one workgroup owns one sample x four
+// channels, turns the sample's M tiles into y = relu(M A ... * scale + shift) (+ residual) IN LDS (the whole
+// D x H x W volume of four channels: 92 KB at 8 x 20 x 36) and, after one barrier, reads the overlapping 6^3
+// input tiles of the next layer back out of LDS and writes their B^T transforms as V.  HBM traffic per
+// layer boundary: M once in, V once out (2 x 134 MB at config 2) instead of M in, y out, y in (through L2,
+// 3.4 x overlapped) and V out.  Both intermediates are in the QUAD-major layout here
+//     V, M   [point][ceil(C/16)][4 quads][tile][4 channels]
+// so that a workgroup's share of a transform point is one contiguous run (tiles of a sample x 16 bytes) and
+// a wave moves 256 contiguous bytes per instruction; wino_gemm_bf16x3 takes either layout (strides).
+// The residual connection (CostRegNetNoDown.forward submodule.py:656-658: output0 is added back three layers
+// later) travels in a private planar layout R [sample][quad][D][H][4][W | 1] = a dump of the workgroup's LDS.
+// Phase 1 is wino_output_stream6 per (tile, channel); phase 2 is wino_input_body with two threads per
+// (tile, channel), LDS instead of x.
+constexpr int MID_THREADS = 512;
+
+template <int HALF>
+__device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __amdgpu_buffer_rsrc_t vr, int voff, int xs,
+                                               const Tiling &g, int Wp, int ch, int z0, int y0, int x0) {
+    constexpr int T = 6, KW = 3, K0 = HALF * KW;
+    float d[T][T][KW];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int z = z0 - 1 + i;
+#pragma unroll
+        for (int jj = 0; jj < T; ++jj) {
+            const int y = y0 - 1 + jj;
+            const bool okzy = (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H;
+            const float *row = ys + ((okzy ? z * g.H + y : 0) * 4 + ch) * Wp;
+            float r[T];
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                const int x = x0 - 1 + k;
+                const bool ok = okzy && (unsigned)x < (unsigned)g.W;
+                const float v = row[ok ? x : 0];
+                r[k] = ok ? v : 0.f;
+            }
+            bt_1d<T>(r);
+#pragma unroll
+            for (int k = 0; k < KW; ++k) d[i][jj][k] = r[K0 + k];
+        }
+        // one depth plane of LDS reads at a time: hoisting all 216 reads (+ their predicates) spills
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            float v[T];
+#pragma unroll
+            for (int jj = 0; jj < T; ++jj) v[jj] = d[i][jj][k];
+            bt_1d<T>(v);
+#pragma unroll
+            for (int jj = 0; jj < T; ++jj) d[i][jj][k] = v[jj];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < T; ++jj) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            float v[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) v[i] = d[i][jj][k];
+            bt_1d<T>(v);
+#pragma unroll
+            for (int i = 0; i < T; ++i)                 // the point offset is uniform: scalar operand of the store
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[i]), vr, voff, ((i * T + jj) * T + K0 + k) * xs, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
+    const float *__restrict__ M, float *__restrict__ V, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ res_in, float *__restrict__ res_out, Tiling g,
+    int C, int nt, int relu) {
+    extern __shared__ float ys[];                       // [D][H][4][Wp]
+    constexpr int T = 6, O = 4;
+    const int Wp = g.W | 1, vol = g.D * g.H * 4 * Wp;
+    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;     // quads with data, quads per transform point
+    const int b = blockIdx.x / nq, cq = blockIdx.x - b * nq;
+    const int nts = g.Td * g.Th * g.Tw, items = nts * 4;
+    const int xs = Q * nt * 16;                         // bytes between transform points
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, 216 * xs, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, 216 * xs, 0x00020000);
+    const size_t blk = ((size_t)b * nq + cq) * vol;     // this workgroup's block of R
+    if (res_in) {
+        for (int i = threadIdx.x * 4; i < vol; i += MID_THREADS * 4) {
+            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(ys + i) = *reinterpret_cast<const f32x4 *>(res_in + blk + i);
+            else for (int e = i; e < vol; ++e) ys[e] = res_in[blk + e];
+        }
+        __syncthreads();
+    }
+    // ---- phase 1: M -> y (A^T along W, H per depth plane of M; D as an accumulation) ----
+#ifndef MID_NO_P1
+    for (int it = threadIdx.x; it < items; it += MID_THREADS) {
+        const int ch = it & 3, tl = it >> 2;
+        const int co = cq * 4 + ch;
+        int bb, z0, y0, x0;
+        tile_coords<O, O, O>(tl, g, bb, z0, y0, x0);
+        const int moff = ((cq * nt + b * nts + tl) * 4 + ch) * 4;
+        float acc[O][O][O];
+#pragma unroll
+        for (int i = 0; i < O; ++i)
+#pragma unroll
+            for (int jj = 0; jj < O; ++jj)
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc[i][jj][k] = 0.f;
+        float p0[T][T], p1[T][T];
+        auto load_plane = [&](float (&p)[T][T], int i) {
+#pragma unroll
+            for (int jj = 0; jj < T; ++jj)
+#pragma unroll
+                for (int k = 0; k < T; ++k)
+                    p[jj][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(mr, moff, ((i * T + jj) * T + k) * xs, 0));
+        };
+        auto consume = [&](float (&p)[T][T], int i) {
+            float a[T][O], h[O][O];
+#pragma unroll
+            for (int jj = 0; jj < T; ++jj) at_1d<T>(p[jj], a[jj]);
+#pragma unroll
+            for (int k = 0; k < O; ++k) {
+                float m[T], o[O];
+#pragma unroll
+                for (int jj = 0; jj < T; ++jj) m[jj] = a[jj][k];
+                at_1d<T>(m, o);
+#pragma unroll
+                for (int jj = 0; jj < O; ++jj) h[jj][k] = o[jj];
+            }
+            const float c0 = AT6_TAB[i][0], c1 = AT6_TAB[i][1], c2 = AT6_TAB[i][2], c3 = AT6_TAB[i][3];
+#pragma unroll
+            for (int jj = 0; jj < O; ++jj)
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    acc[0][jj][k] = fmaf(c0, h[jj][k], acc[0][jj][k]);
+                    acc[1][jj][k] = fmaf(c1, h[jj][k], acc[1][jj][k]);
+                    acc[2][jj][k] = fmaf(c2, h[jj][k], acc[2][jj][k]);
+                    acc[3][jj][k] = fmaf(c3, h[jj][k], acc[3][jj][k]);
+                }
+        };
+        load_plane(p0, 0);
+#pragma unroll 1
+        for (int i = 0; i < T; i += 2) {
+            load_plane(p1, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(p0, i);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < T) load_plane(p0, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(p1, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float sc = co < C ? scale[co] : 0.f, sh = co < C ? shift[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < O; ++i)
+#pragma unroll
+            for (int jj = 0; jj < O; ++jj) {
+                const int z = z0 + i, yy = y0 + jj;
+                float *row = ys + ((z * g.H + yy) * 4 + ch) * Wp + x0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    if (z < g.D && yy < g.H && x0 + k < g.W) {
+                        float v = fmaf(acc[i][jj][k], sc, sh);
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (res_in) v += row[k];
+                        row[k] = v;
+                    }
+                }
+            }
+    }
+#endif
+    __syncthreads();
+    if (res_out) {
+        for (int i = threadIdx.x * 4; i < vol; i += MID_THREADS * 4) {
+            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(res_out + blk + i) = *reinterpret_cast<const f32x4 *>(ys + i);
+            else for (int e = i; e < vol; ++e) res_out[blk + e] = ys[e];
+        }
+    }
+    // ---- phase 2: y -> V (B^T along W, H, D), two threads per (tile, channel): each keeps three of the six
+    // W-transformed columns ----
+#ifndef MID_NO_P2
+    const int itp = (items + 63) & ~63;                 // the half is uniform within a wave
+    for (int it = threadIdx.x; it < 2 * itp; it += MID_THREADS) {
+        const int half = it >= itp, id = it - half * itp;
+        if (id >= items) continue;
+        const int ch = id & 3, tl = id >> 2;
+        int bb, z0, y0, x0;
+        tile_coords<O, O, O>(tl, g, bb, z0, y0, x0);
+        const int voff = ((cq * nt + b * nts + tl) * 4 + ch) * 4;
+        if (half == 0) mid_input_half<0>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
+        else mid_input_half<1>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
+    }
+#endif
+}
+
 // ------------------------------ batched GEMM  M[xi] = V[xi] * U[xi] ----------------------
 // K = Ci is short (216), so an LDS-staged tile pipeline (the first version of this kernel: 192x224
 // tiles, double-buffered LDS as conv3d_k3_igemm) spent a quarter of its time filling and draining
@@ -752,7 +945,10 @@ __global__ void wino_split_weights(const float *__restrict__ U, int *__restrict_
 template <int WM, int NPAIR>
 __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_bf16x3(
     const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
-    int Co, int np, int swz) {
+    int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs) {
+    // v_ms / v_kqs, m_ms / m_kqs: bytes between consecutive tiles and between the four 4-channel groups of a
+    // 16-channel chunk in V and in M: (64, 16) = the chunk-major layout [chunk][tile][16] of the head of this
+    // file, (16, 16 nt) = the quad-major layout [chunk][4 quads][tile][4] of wino_mid_transform
     constexpr int TM = 3, TN = 7, OOB = 0x7fffffff, RING = 4;   // ring of 4 operand tiles: tile s + 3 (AHEAD) in flight while s is multiplied
     const int mblocks = gridDim.x, ngroups = gridDim.y;
     int pt = blockIdx.y, mb = blockIdx.x;
@@ -771,11 +967,12 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * v_point, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ubb, 0, np * u_point, 0x00020000);
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * m_point, 0x00020000);
-    int v_row[TM];
+    int v_row[TM], m_row[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + i * 16 + i16;
-        v_row[i] = m < nt ? m * 64 : OOB;
+        v_row[i] = m < nt ? m * v_ms : OOB;
+        m_row[i] = m < nt ? m * m_ms : OOB;
     }
     const int u_lane = (wn * (W_BN / 2) + i16) * 64 + kq * 16 + pt * u_point;
 
@@ -792,7 +989,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
                 ur, p < NPAIR ? u_lane + p * u_pair + term * u_term + j * 1024 : OOB, 0, 0);
     };
     auto load_v = [&](int p) {
-        const int vb = pt * v_point + kq * 16;
+        const int vb = pt * v_point + kq * v_kqs;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -845,7 +1042,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const int pb = pt * m_point + kq * 16;
+    const int pb = pt * m_point + kq * m_kqs;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int cg = wn * TN + j;
@@ -854,7 +1051,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
             const f32x4 a = acc[j][i];
             __builtin_amdgcn_raw_buffer_store_b128(
                 i32x4{__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])},
-                mr, cg < CG && v_row[i] != OOB ? v_row[i] + pb + cg * v_chunk : OOB, 0, 0);
+                mr, cg < CG && m_row[i] != OOB ? m_row[i] + pb + cg * v_chunk : OOB, 0, 0);
         }
     }
 }
@@ -883,16 +1080,18 @@ int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co
     return decnet_launch_status();
 }
 
+// v_quad / m_quad: V / M in the quad-major layout (wino_gemm_bf16x3 only)
 int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
-                  hipStream_t s) {
+                  hipStream_t s, int v_quad = 0, int m_quad = 0) {
     static const int tile_env = [] { const char *e = getenv("DECNET_WINO_TILE"); return e ? atoi(e) : 0; }();
     if (gemm_bf16x3() && Ci == 216) {
         static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
         const int *Ub = reinterpret_cast<const int *>(U + (size_t)np * pad16(Ci) * W_BN);   // split copy behind U^T
         hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(nt, 96), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
-                           Co, np, swz);
+                           Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
         return decnet_launch_status();
     }
+    if (v_quad || m_quad) return DECNET_ERR_UNSUPPORTED;
     static const int gemm_static = [] { const char *e = getenv("DECNET_WINO_GEMM"); return e && !strcmp(e, "static") ? 1 : 0; }();
     if (!gemm_static && !tile_env && Ci == 216 && np >= 8) {
         hipLaunchKernelGGL((wino_gemm_persist<13, 2>), dim3(512), dim3(256), 0, s, V, U, M, nt, Ci, Co, np);
@@ -942,6 +1141,62 @@ int conv_variant(const float *x, const float *u, const float *scale, const float
         hipLaunchKernelGGL((wino_output_transform<TD, TH, TW, KS>), dim3((unsigned)((n + 255) / 256), KS),
                            dim3(256), 0, s, M, scale, shift, residual, y, g, Co, relu, t_lo, nt,
                            (int)((size_t)B * D * H * W * Co * 4));
+        if ((rc = decnet_launch_status())) return rc;
+    }
+    return DECNET_OK;
+}
+
+// ---- a stack of C -> C layers with the activations between them kept on chip (wino_mid_transform) ----
+size_t stack_lds_bytes(int D, int H, int W) { return (size_t)D * H * 4 * (W | 1) * 4; }
+size_t stack_residual_floats(int B, int D, int H, int W, int C) { return (size_t)B * ((C + 3) / 4) * D * H * 4 * (W | 1); }
+
+// 1 when the fused stack can run this shape: F(4,3)^3, the bf16x3 GEMM (C = 216), every tile in one chunk,
+// one sample x four channels in LDS
+bool stack_ok(int B, int D, int H, int W, int C, int variant) {
+    static const int off = [] { const char *e = getenv("DECNET_WINO_STACK"); return e && !strcmp(e, "0") ? 1 : 0; }();
+    if (off || variant != 2 || !gemm_bf16x3() || C != 216) return false;
+    if (stack_lds_bytes(D, H, W) > 160 * 1024) return false;
+    const double T = (double)B * ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 4);
+    if (T >= 2147483648.0 || chunk_tiles((int)T, C, 216) < (int)T) return false;
+    return (double)T * pad16(C) * 4 * 216 < 2147483647.0 && (double)B * D * H * W * C * 4 < 2147483647.0;
+}
+
+int conv_stack(const float *x, const float *const *u, const float *const *scale, const float *const *shift,
+               int n_layers, int res_src, int res_dst, float *y, float *workspace, float *R, int B, int D, int H,
+               int W, int C, hipStream_t s) {
+    constexpr int NP = 216;
+    Tiling g{D, H, W, ceil_div(D, 4), ceil_div(H, 4), ceil_div(W, 4)};
+    const int nt = B * g.Td * g.Th * g.Tw;
+    float *V = workspace, *M = workspace + (size_t)NP * nt * pad16(C);
+    const int bytes = (int)((size_t)B * D * H * W * C * 4);
+    const size_t lds = stack_lds_bytes(D, H, W);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void *)wino_mid_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return DECNET_ERR_UNSUPPORTED;
+        }
+        lds_set = lds;
+    }
+    const int ith = C >= 256 ? 256 : (C + 63) / 64 * 64;
+    hipLaunchKernelGGL((wino_input_transform<6, 6, 6, 1>), dim3((unsigned)(8 * ((nt + 7) / 8)), (unsigned)ceil_div(C, ith)),
+                       dim3(ith), 0, s, x, V, g, C, 0, nt, bytes);
+    int rc = decnet_launch_status();
+    if (rc) return rc;
+    for (int i = 0; i < n_layers; ++i) {
+        const bool last = i == n_layers - 1;
+        // V of layer 0 comes from wino_input_transform (chunk major), M of the last layer goes to
+        // wino_output_transform (chunk major); everything between is quad major
+        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0, !last))) return rc;
+        if (last) {
+            const size_t n = (size_t)nt * pad16(C);
+            hipLaunchKernelGGL((wino_output_transform<6, 6, 6, 1>), dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, s,
+                               M, scale[i], shift[i], (const float *)nullptr, y, g, C, 1, 0, nt, bytes);
+        } else {
+            hipLaunchKernelGGL(wino_mid_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), lds, s, M, V,
+                               scale[i], shift[i], i == res_dst ? R : (const float *)nullptr,
+                               i == res_src ? R : (float *)nullptr, g, C, nt, 1);
+        }
         if ((rc = decnet_launch_status())) return rc;
     }
     return DECNET_OK;
@@ -1020,6 +1275,35 @@ size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, i
     if (T >= 2147483648.0) return 0;
     const int nt = chunk_tiles((int)T, Ci > Co ? Ci : Co, np);
     return (size_t)np * nt * ((size_t)pad16(Ci) + pad16(Co));
+}
+
+/* n_layers >= 2 consecutive Conv3d(k3,s1,p1) + BN + ReLU units C -> C (u[i] / scale[i] / shift[i] as for
+ * decnet_conv3d_wino_bn_act) with the activations BETWEEN the layers kept on chip: the output transform of layer
+ * i and the input transform of layer i + 1 are one kernel, so x is read once, y written once, and per layer
+ * boundary only the transformed tiles touch HBM.  res_src / res_dst (or -1, -1): the output of layer res_src is
+ * added to the output of layer res_dst (after its ReLU), 0 <= res_src < res_dst < n_layers - 1
+ * (CostRegNetNoDown.forward submodule.py:653-658).  workspace: decnet_conv3d_wino_stack_workspace_floats floats.
+ * Returns DECNET_ERR_UNSUPPORTED (nothing launched) for shapes the fused kernels do not cover -- callers then run the
+ * layers one by one (decnet_stage0_forward does). */
+size_t decnet_conv3d_wino_stack_workspace_floats(int B, int D, int H, int W, int C, int variant) {
+    if (B < 1 || D < 1 || H < 1 || W < 1 || C < 1 || !stack_ok(B, D, H, W, C, variant)) return 0;
+    const size_t w = decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant);
+    return w ? ((w + 63) & ~(size_t)63) + stack_residual_floats(B, D, H, W, C) : 0;
+}
+
+int decnet_conv3d_wino_stack_bn_act(const float *x, const float *const *u, const float *const *scale,
+                                    const float *const *shift, int n_layers, int res_src, int res_dst, float *y,
+                                    float *workspace, int B, int D, int H, int W, int C, int variant, void *stream) {
+    if (!x || !u || !scale || !shift || !y || !workspace) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    for (int i = 0; i < n_layers; ++i)
+        if (!u[i] || !scale[i] || !shift[i]) return DECNET_ERR_NULL_POINTER;
+    if ((res_src < 0) != (res_dst < 0)) return DECNET_ERR_BAD_SHAPE;
+    if (res_src >= 0 && !(res_src < res_dst && res_dst < n_layers - 1)) return DECNET_ERR_UNSUPPORTED;
+    if (n_layers < 2 || !stack_ok(B, D, H, W, C, variant)) return DECNET_ERR_UNSUPPORTED;
+    const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
+    return conv_stack(x, u, scale, shift, n_layers, res_src, res_dst, y, workspace, workspace + w, B, D, H, W, C,
+                      (hipStream_t)stream);
 }
 
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale, const float *shift,

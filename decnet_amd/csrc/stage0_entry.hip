@@ -23,6 +23,9 @@ size_t decnet_stage0_workspace_floats(int B, int C, int H, int W, int D, int var
     if (variant <= 2) {
         wino = decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant);
         if (!wino) return 0;
+        // the fused stack (decnet_conv3d_wino_stack_bn_act) keeps its residual plane behind the V/M scratch
+        const size_t stack = decnet_conv3d_wino_stack_workspace_floats(B, D, H, W, C, variant);
+        if (stack > wino) wino = stack;
     }
     // cost volume + three activation buffers (+ the Winograd V/M scratch); the last layer's tap products
     // (decnet_conv3d_cout1_workspace_floats) reuse an activation buffer that is free by then when they fit
@@ -42,7 +45,9 @@ int decnet_stage0_forward(const float *left, const float *right, const decnet_st
     if (!decnet_stage0_workspace_floats(B, C, H, W, D, variant)) return DECNET_ERR_UNSUPPORTED;
     const size_t act = align64((size_t)B * D * H * W * C);
     float *cv = workspace, *a = cv + act, *b = a + act, *c = b + act, *ws = c + act;
-    const size_t wino = variant <= 2 ? align64(decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant)) : 0;
+    const size_t stack = variant <= 2 ? decnet_conv3d_wino_stack_workspace_floats(B, D, H, W, C, variant) : 0;
+    size_t wino = variant <= 2 ? decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) : 0;
+    wino = align64(stack > wino ? stack : wino);
     const size_t last = decnet_conv3d_cout1_workspace_floats(B, D, H, W);
     float *t_last = last > act ? ws + wino : a;
 
@@ -55,6 +60,17 @@ int decnet_stage0_forward(const float *left, const float *right, const decnet_st
         return decnet_conv3d_bn_act(src, p->w[i], p->scale[i], p->shift[i], res, dst, B, D, H, W, C, C, 1, stream);
     };
     // CostRegNetNoDown.forward submodule.py:650-662
+    rc = DECNET_ERR_UNSUPPORTED;
+    if (stack)                                          // all seven layers with the activations between them on chip
+        rc = decnet_conv3d_wino_stack_bn_act(cv, p->w, p->scale, p->shift, 7, 1, 4, c, ws, B, D, H, W, C, variant, stream);
+    if (rc == DECNET_OK) {
+        if (C <= 256 && D <= 256)
+            return decnet_conv3d_cout1_softargmax_ws(c, p->w_last, p->scale_last, p->shift_last, reg, pred, t_last, B,
+                                                     D, H, W, C, stream);
+        return decnet_conv3d_cout1_softargmax(c, p->w_last, p->scale_last, p->shift_last, reg, pred, B, D, H, W, C,
+                                              stream);
+    }
+    if (rc != DECNET_ERR_UNSUPPORTED) return rc;
     if ((rc = conv(0, cv, a, nullptr))) return rc;
     if ((rc = conv(1, a, c, nullptr))) return rc;       // c = output0
     if ((rc = conv(2, c, a, nullptr))) return rc;

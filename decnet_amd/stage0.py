@@ -304,13 +304,14 @@ class CostRegNetNoDown(nn.Module):
         with torch.cuda.device(dev):
             st = _stream(x)
             # CostRegNetNoDown.forward submodule.py:650-662
-            conv(0, x, a)
-            conv(1, a, c)                 # c = output0
-            conv(2, c, a)
-            conv(3, a, b)
-            conv(4, b, a, res=c)          # conv1(output0) + output0
-            conv(5, a, b)
-            conv(6, b, c)
+            if not self._run_stack(L, P, x, c, B, D, H, W, C, algo, st):
+                conv(0, x, a)
+                conv(1, a, c)                 # c = output0
+                conv(2, c, a)
+                conv(3, a, b)
+                conv(4, b, a, res=c)          # conv1(output0) + output0
+                conv(5, a, b)
+                conv(6, b, c)
             p = P[7]
             regp = reg.data_ptr() if reg is not None else None
             need = L.decnet_conv3d_cout1_workspace_floats(B, D, H, W)
@@ -325,6 +326,33 @@ class CostRegNetNoDown(nn.Module):
                                                       regp, pred.data_ptr(), B, D, H, W, p["Ci"], st)
                 _lib.check(rc, "decnet_conv3d_cout1_softargmax")
         return reg, (pred if want_pred else None)
+
+    def _run_stack(self, L, P, x, out, B, D, H, W, C, algo, st):
+        """The seven C -> C units as ONE fused stack (decnet_conv3d_wino_stack_bn_act: the activations between the
+        layers stay on chip); False when the shape is not covered (the caller then runs the layers one by one).
+        DECNET_WINO_STACK=0 turns it off."""
+        if algo not in WINO_VARIANT or os.environ.get("DECNET_WINO_STACK", "1") == "0":
+            return False
+        if any(not p["relu"] or p["Ci"] != C or p["Co"] != C for p in P[:7]):
+            return False
+        var = WINO_VARIANT[algo]
+        n = L.decnet_conv3d_wino_stack_workspace_floats(B, D, H, W, C, var)
+        if n == 0:
+            return False
+        dev = x.device
+        wsp = self._ws.get(("wino", dev))
+        if wsp is None or wsp.numel() < n:
+            wsp = torch.empty(n, dtype=torch.float32, device=dev)
+            self._ws[("wino", dev)] = wsp
+        import ctypes
+        arr = ctypes.c_void_p * 7
+        u, sc, sh = (arr(*[P[i][k].data_ptr() for i in range(7)]) for k in ("u", "scale", "shift"))
+        rc = L.decnet_conv3d_wino_stack_bn_act(x.data_ptr(), u, sc, sh, 7, 1, 4, out.data_ptr(), wsp.data_ptr(),
+                                               B, D, H, W, C, var, st)
+        if rc == _lib.UNSUPPORTED:
+            return False
+        _lib.check(rc, "decnet_conv3d_wino_stack_bn_act")
+        return True
 
     def forward(self, x):
         reg, _ = self.run_ndhwc(_to_ndhwc(x), want_reg=True, want_pred=False)

@@ -155,6 +155,18 @@ int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale
                               float *workspace, int B, int D, int H, int W, int Ci, int Co,
                               int relu, int variant, void *stream);
 
+/* A stack of n_layers >= 2 consecutive C -> C Conv3dUnits (submodule.py:115-123) with the activations between the
+ * layers kept on chip: one kernel does the output transform of layer i (BN, ReLU, residual) into LDS and the input
+ * transform of layer i + 1 out of it.  u / scale / shift: per-layer pointers as for decnet_conv3d_wino_bn_act.
+ * res_src, res_dst: the output of layer res_src is added to the output of layer res_dst after its ReLU
+ * (CostRegNetNoDown.forward submodule.py:653-658: 1 and 4), or -1, -1; needs res_src < res_dst < n_layers - 1.
+ * DECNET_ERR_UNSUPPORTED (nothing launched; decnet_conv3d_wino_stack_workspace_floats returns 0) when the fused
+ * kernels do not cover the shape: variant 2, C = 216, one sample x 4 channels of the volume <= 160 KB of LDS. */
+size_t decnet_conv3d_wino_stack_workspace_floats(int B, int D, int H, int W, int C, int variant);
+int decnet_conv3d_wino_stack_bn_act(const float *x, const float *const *u, const float *const *scale,
+                                    const float *const *shift, int n_layers, int res_src, int res_dst, float *y,
+                                    float *workspace, int B, int D, int H, int W, int C, int variant, void *stream);
+
 /* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
  * over disp_samples = arange(D) (submodule.py:766-777):
  *   reg[b,d,y,x]  = conv(x)[b,d,y,x] * scale + shift        (optional output, may be NULL)

@@ -1,0 +1,158 @@
+"""The fused stack of Winograd Conv3d layers (decnet_conv3d_wino_stack_bn_act: output transform of layer i + input
+transform of layer i + 1 as one kernel, activations between the layers in LDS) against the same layers run one by one
+(decnet_conv3d_wino_bn_act) and against torch float64 on the CPU.  -m gpu.
+
+Both paths do the same fp32 arithmetic in a different order only inside the transforms' epilogues, so they must agree
+closely but not bitwise (the compiler contracts the transforms' multiply-adds differently in the two kernels, and seven
+layers amplify that): 1e-5 * max|y| per stack (measured <= 3.5e-6 after seven layers); against float64 the stack is held to the
+layer tests' bound (tests/test_stage0_gpu.py: 2e-4 * max|reg| on the regularised volume).
+"""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from oracle import stage0 as o0
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import decnet_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+def _layers(n, C, dev, seed):
+    from decnet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        w = (torch.randn(C, C, 3, 3, 3, generator=g) * (2.0 / (27 * C)) ** 0.5).to(dev)
+        scale = (0.5 + torch.rand(C, generator=g)).to(dev)
+        shift = (0.2 * torch.randn(C, generator=g)).to(dev)
+        u = torch.empty(L.decnet_conv3d_wino_weight_floats(C, 2), dtype=torch.float32, device=dev)
+        _lib.check(L.decnet_conv3d_wino_pack_weight(w.data_ptr(), u.data_ptr(), C, C, 2, None), "pack")
+        out.append(dict(w=w, u=u, scale=scale, shift=shift))
+    torch.cuda.synchronize()
+    return out
+
+
+def _one_by_one(layers, x, res_src, res_dst):
+    from decnet_amd import _lib
+    L = _lib.lib()
+    B, D, H, W, C = x.shape
+    ws = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, 2), dtype=torch.float32, device=x.device)
+    cur, keep = x, None
+    for i, p in enumerate(layers):
+        y = torch.empty_like(x)
+        r = keep.data_ptr() if (i == res_dst and keep is not None) else None
+        _lib.check(L.decnet_conv3d_wino_bn_act(cur.data_ptr(), p["u"].data_ptr(), p["scale"].data_ptr(),
+                                               p["shift"].data_ptr(), r, y.data_ptr(), ws.data_ptr(), B, D, H, W, C, C,
+                                               1, 2, None), "layer %d" % i)
+        if i == res_src:
+            keep = y
+        cur = y
+    torch.cuda.synchronize()
+    return cur
+
+
+def _stack(layers, x, res_src, res_dst):
+    from decnet_amd import _lib
+    L = _lib.lib()
+    B, D, H, W, C = x.shape
+    n = L.decnet_conv3d_wino_stack_workspace_floats(B, D, H, W, C, 2)
+    assert n > 0, "shape not covered by the fused stack"
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    y = torch.full_like(x, float("nan"))
+    arr = ctypes.c_void_p * len(layers)
+    u, sc, sh = (arr(*[p[k].data_ptr() for p in layers]) for k in ("u", "scale", "shift"))
+    _lib.check(L.decnet_conv3d_wino_stack_bn_act(x.data_ptr(), u, sc, sh, len(layers), res_src, res_dst, y.data_ptr(),
+                                                 ws.data_ptr(), B, D, H, W, C, 2, None), "stack")
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("shape,n,res", [((2, 8, 20, 36), 7, (1, 4)),      # config 2's volume, CostRegNetNoDown's wiring
+                                         ((1, 6, 7, 10), 4, (0, 2)),       # ragged tiles on every axis
+                                         ((3, 4, 4, 4), 2, (-1, -1)),      # one tile per sample, no residual
+                                         ((1, 10, 13, 41), 3, (-1, -1)),   # Wp = W (odd), partial tiles
+                                         ((2, 5, 9, 8), 5, (1, 3))])
+def test_stack_matches_layer_by_layer(dev, shape, n, res):
+    B, D, H, W = shape
+    C = 216
+    layers = _layers(n, C, dev, seed=100 + n)
+    x = torch.randn(B, D, H, W, C, generator=torch.Generator().manual_seed(7)).to(dev)
+    ref = _one_by_one(layers, x, *res)
+    got = _stack(layers, x, *res)
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+
+
+def test_stack_vs_torch_float64(dev):
+    B, D, H, W, C, n = 1, 6, 6, 9, 216, 3
+    layers = _layers(n, C, dev, seed=5)
+    x = torch.randn(B, D, H, W, C, generator=torch.Generator().manual_seed(8)).to(dev)
+    got = _stack(layers, x, 0, 1).cpu().double()
+    cur, keep = x.cpu().double().permute(0, 4, 1, 2, 3), None
+    for i, p in enumerate(layers):
+        y = torch.nn.functional.conv3d(cur, p["w"].cpu().double(), padding=1)
+        y = torch.relu(y * p["scale"].cpu().double().view(1, -1, 1, 1, 1) + p["shift"].cpu().double().view(1, -1, 1, 1, 1))
+        if i == 1:
+            y = y + keep
+        if i == 0:
+            keep = y
+        cur = y
+    ref = cur.permute(0, 2, 3, 4, 1)
+    err = float((got - ref).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()), err
+
+
+def test_unsupported_shapes_launch_nothing(dev):
+    from decnet_amd import _lib
+    L = _lib.lib()
+    assert L.decnet_conv3d_wino_stack_workspace_floats(1, 8, 20, 36, 64, 2) == 0       # C != 216
+    assert L.decnet_conv3d_wino_stack_workspace_floats(1, 8, 20, 36, 216, 1) == 0      # not F(4,3)^3
+    assert L.decnet_conv3d_wino_stack_workspace_floats(1, 16, 40, 72, 216, 2) == 0     # one sample x 4 channels > LDS
+    layers = _layers(2, 216, dev, seed=1)
+    x = torch.zeros(1, 16, 40, 72, 216, device=dev)
+    arr = ctypes.c_void_p * 2
+    u, sc, sh = (arr(*[p[k].data_ptr() for p in layers]) for k in ("u", "scale", "shift"))
+    rc = L.decnet_conv3d_wino_stack_bn_act(x.data_ptr(), u, sc, sh, 2, -1, -1, x.data_ptr(), x.data_ptr(), 1, 16, 40, 72,
+                                           216, 2, None)
+    assert rc == _lib.UNSUPPORTED
+    rc = L.decnet_conv3d_wino_stack_bn_act(x.data_ptr(), u, sc, sh, 2, 0, 1, x.data_ptr(), x.data_ptr(), 1, 4, 4, 4, 216,
+                                           2, None)
+    assert rc == _lib.UNSUPPORTED                        # a residual into the last layer is not covered
+
+
+def test_module_uses_the_stack_and_agrees_with_the_unfused_path(dev):
+    import decnet_amd
+    C, D = 216, 8
+    reg = decnet_amd.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func="cor")
+    params = o0.random_params(C, 3)
+    for u, p in zip(reg.units(), params):
+        u.conv.weight.data = p["w"].clone()
+        g, b, m, v = p["bn"]
+        u.bn.weight.data, u.bn.bias.data = g.clone(), b.clone()
+        u.bn.running_mean.data, u.bn.running_var.data = m.clone(), v.clone()
+    reg = reg.to(dev).eval()
+    x = torch.randn(2, D, 10, 18, C, generator=torch.Generator().manual_seed(2)).to(dev)
+    old = os.environ.get("DECNET_WINO_STACK")
+    try:
+        with torch.no_grad():
+            os.environ["DECNET_WINO_STACK"] = "0"
+            r0, p0 = reg.run_ndhwc(x)
+            os.environ["DECNET_WINO_STACK"] = "1"
+            r1, p1 = reg.run_ndhwc(x)
+    finally:
+        if old is None:
+            os.environ.pop("DECNET_WINO_STACK", None)
+        else:
+            os.environ["DECNET_WINO_STACK"] = old
+    assert float((r0 - r1).abs().max()) <= 1e-5 * max(1.0, float(r0.abs().max()))
+    assert float((p0 - p1).abs().max()) <= 1e-3       # random weights: a nearly flat volume under the soft-argmax
