@@ -526,6 +526,10 @@ __device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __a
     }
 #pragma unroll
     for (int jj = 0; jj < T; ++jj) {
+        // (opaque copy of the point stride per row: otherwise all 108 scalar offsets are computed up front and
+        // spill out of the scalar registers into vector lanes)
+        int xo = xs;
+        asm volatile("" : "+s"(xo));
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
             float v[T];
@@ -534,7 +538,7 @@ __device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __a
             bt_1d<T>(v);
 #pragma unroll
             for (int i = 0; i < T; ++i)                 // the point offset is uniform: scalar operand of the store
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[i]), vr, voff, ((i * T + jj) * T + K0 + k) * xs, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[i]), vr, voff, ((i * T + jj) * T + K0 + k) * xo, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -578,11 +582,14 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
                 for (int k = 0; k < O; ++k) acc[i][jj][k] = 0.f;
         float p0[T][T], p1[T][T];
         auto load_plane = [&](float (&p)[T][T], int i) {
+            int xo = xs;                                // opaque per plane, see mid_input_half
+            asm volatile("" : "+s"(xo));
+            const int so = i * (T * T) * xo;
 #pragma unroll
             for (int jj = 0; jj < T; ++jj)
 #pragma unroll
                 for (int k = 0; k < T; ++k)
-                    p[jj][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(mr, moff, ((i * T + jj) * T + k) * xs, 0));
+                    p[jj][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(mr, moff, so + (jj * T + k) * xo, 0));
         };
         auto consume = [&](float (&p)[T][T], int i) {
             float a[T][O], h[O][O];

@@ -79,7 +79,7 @@ def _stack(layers, x, res_src, res_dst):
 @pytest.mark.parametrize("shape,n,res", [((2, 8, 20, 36), 7, (1, 4)),      # config 2's volume, CostRegNetNoDown's wiring
                                          ((1, 6, 7, 10), 4, (0, 2)),       # ragged tiles on every axis
                                          ((3, 4, 4, 4), 2, (-1, -1)),      # one tile per sample, no residual
-                                         ((1, 10, 13, 41), 3, (-1, -1)),   # Wp = W (odd), partial tiles
+                                         ((1, 10, 9, 21), 3, (-1, -1)),    # odd W, partial tiles
                                          ((2, 5, 9, 8), 5, (1, 3))])
 def test_stack_matches_layer_by_layer(dev, shape, n, res):
     B, D, H, W = shape

@@ -5,7 +5,7 @@ import decnet_amd
 from decnet_amd import _lib
 L=_lib.lib()
 dev=torch.device("cuda:0")
-B,D,H,W,C=8,8,20,36,216
+B=int(os.environ.get("SB","8")); D,H,W,C=8,20,36,216
 g=torch.Generator().manual_seed(0)
 layers=[]
 for i in range(7):
