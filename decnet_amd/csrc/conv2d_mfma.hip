@@ -63,6 +63,27 @@ __device__ __forceinline__ void split3(float x, int &h, int &m, int &l) {
     l = __float_as_int((float)(__bf16)(r1 - __int_as_float(m)));
 }
 
+// eight values -> the three packed operand registers sets {hi, mid, lo}[4] (pairs (x[2e], x[2e+1]) share a register):
+// the same terms as split3, two per v_cvt_pk_bf16_f32 -- the packed pair IS the operand register, and a term's float
+// value is a shift / a mask of it (no v_perm_b32, half the conversions, packed subtractions)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pack_bf16(float a, float b) {
+    return __builtin_bit_cast(int, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ void split3x8(const float (&x)[8], i32x4 &th, i32x4 &tm, i32x4 &tl) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = x[2 * e], x1 = x[2 * e + 1];
+        const int h = pack_bf16(x0, x1);
+        const float r0 = x0 - __int_as_float(h << 16), r1 = x1 - __int_as_float(h & 0xffff0000);
+        const int m = pack_bf16(r0, r1);
+        th[e] = h;
+        tm[e] = m;
+        tl[e] = pack_bf16(r0 - __int_as_float(m << 16), r1 - __int_as_float(m & 0xffff0000));
+    }
+}
+
 // w [Cout][Cin][KT] -> wp[chunk][tap][j][n tile][lane] (16 bytes: the lane's 8 bf16 of the B operand)
 // tr: w is a ConvTranspose2d weight [Cin][Cout / 9][3][3] read as the 1 x 1 convolution to n = 9 co + 3 ky + kx
 __global__ void conv2d_mfma_pack(const float *__restrict__ w, i32x4 *__restrict__ wp, int Cin, int Cout, int KT,
@@ -227,16 +248,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
         for (int u = 0; u < NU; ++u) {
             const int p = (tid & 127) + 128 * u;
             if (p >= P) break;
-            int h[8], m[8], l[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) split3(raw[u][e], h[e], m[e], l[e]);
             i32x4 th, tm, tl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                th[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302);
-                tm[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302);
-                tl[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302);
-            }
+            split3x8(raw[u], th, tm, tl);
             smem[(0 * 2 + sg) * P + p] = th;
             smem[(1 * 2 + sg) * P + p] = tm;
             smem[(2 * 2 + sg) * P + p] = tl;
@@ -358,16 +371,8 @@ __global__ __launch_bounds__(2 * THREADS, 1) void conv2d_mfma_pc(
                 for (int u = 0; u < NU; ++u) {
                     const int p = (lt & 127) + 128 * u;
                     if (p >= P) break;
-                    int h[8], m[8], l[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) split3(raw[u][e], h[e], m[e], l[e]);
                     i32x4 th, tm, tl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        th[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302);
-                        tm[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302);
-                        tl[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302);
-                    }
+                    split3x8(raw[u], th, tm, tl);
                     tile[(0 * 2 + sg) * P + p] = th;
                     tile[(1 * 2 + sg) * P + p] = tm;
                     tile[(2 * 2 + sg) * P + p] = tl;

@@ -44,6 +44,9 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+#ifndef W3_ABLATE
+#define W3_ABLATE 0              // wino_gemm_bf16x3, timing only: 1 no V split | 2 U^T always L1 hits | 3 no U^T loads | 4 one MFMA of six
+#endif
 #ifndef DECNET_WINO_OUT_STREAM
 #define DECNET_WINO_OUT_STREAM 1
 #endif
@@ -911,22 +914,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // flight during the whole current pair.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// {bf16(b), bf16(a)} as one register, round to nearest even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ int pack_bf16(float a, float b) {
+    return __builtin_bit_cast(int, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+
 __device__ __forceinline__ void split3(const f32x4 &a, const f32x4 &b, i32x4 &hi, i32x4 &mid, i32x4 &lo) {
-    // 8 values (a: chunk 2p, b: chunk 2p+1) -> three packed 8 x bf16 operands
-    float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    int h[8], m[8], l[8];
+    // 8 values (a: chunk 2p, b: chunk 2p+1) -> three packed 8 x bf16 operands; round-to-nearest terms (see
+    // csrc/conv2d_mfma.hip).  Two values per conversion: the packed pair IS the operand register, and the float value
+    // of a term is a shift / a mask of it
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {                       // round-to-nearest terms (v_cvt_pk_bf16_f32): see csrc/conv2d_mfma.hip
-        h[e] = __float_as_int((float)(__bf16)x[e]);
-        const float r1 = x[e] - __int_as_float(h[e]);
-        m[e] = __float_as_int((float)(__bf16)r1);
-        l[e] = __float_as_int((float)(__bf16)(r1 - __int_as_float(m[e])));
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {                       // {x[2e+1][31:16], x[2e][31:16]}
-        hi[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302);
-        mid[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302);
-        lo[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302);
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = x[2 * e], x1 = x[2 * e + 1];
+        const int h = pack_bf16(x0, x1);
+        const float r0 = x0 - __int_as_float(h << 16), r1 = x1 - __int_as_float(h & 0xffff0000);
+        const int m = pack_bf16(r0, r1);
+        const float s0 = r0 - __int_as_float(m << 16), s1 = r1 - __int_as_float(m & 0xffff0000);
+        hi[e] = h;
+        mid[e] = m;
+        lo[e] = pack_bf16(s0, s1);
     }
 }
 
@@ -949,14 +957,14 @@ __global__ void wino_split_weights(const float *__restrict__ U, int *__restrict_
         *reinterpret_cast<i32x4 *>(Ub + ((((size_t)pt * NP2 + pair) * 3 + term) * W_BN + co) * 16 + 4 * kq) = t[term];
 }
 
-template <int WM, int NPAIR>
-__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_bf16x3(
+template <int WM, int NPAIR, int TM = 3>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3 ? 1 : 2, TM > 3 ? 1 : 2))) void wino_gemm_bf16x3(
     const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
     int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs) {
     // v_ms / v_kqs, m_ms / m_kqs: bytes between consecutive tiles and between the four 4-channel groups of a
     // 16-channel chunk in V and in M: (64, 16) = the chunk-major layout [chunk][tile][16] of the head of this
     // file, (16, 16 nt) = the quad-major layout [chunk][4 quads][tile][4] of wino_mid_transform
-    constexpr int TM = 3, TN = 7, OOB = 0x7fffffff, RING = 4;   // ring of 4 operand tiles: tile s + 3 (AHEAD) in flight while s is multiplied
+    constexpr int TN = 7, OOB = 0x7fffffff, RING = 4;   // ring of 4 operand tiles: tile s + 3 (AHEAD) in flight while s is multiplied
     const int mblocks = gridDim.x, ngroups = gridDim.y;
     int pt = blockIdx.y, mb = blockIdx.x;
     if (swz) {
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, kq = lane >> 4;
-    const int m0 = (mb * WM + wm) * 48;
+    const int m0 = (mb * WM + wm) * (TM * 16);
     if (m0 >= nt) return;
     const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;
     const int v_chunk = nt * 64, v_point = KC * v_chunk, m_point = CG * v_chunk;
@@ -1023,15 +1031,28 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
 #pragma unroll
+#if W3_ABLATE == 1                                      // timing only: no split of V
+        for (int i = 0; i < TM; ++i) {
+            vs[i][0] = __builtin_bit_cast(i32x4, vf[i][0]); vs[i][1] = __builtin_bit_cast(i32x4, vf[i][1]);
+            vs[i][2] = vs[i][0] ^ vs[i][1];
+        }
+#else
         for (int i = 0; i < TM; ++i) split3(vf[i][0], vf[i][1], vs[i][0], vs[i][1], vs[i][2]);
+#endif
         load_v(p + 1);                                  // vf is free again
 #pragma unroll
         for (int g = 0; g < (TN + 1) / 2; ++g) {        // tiles 2g, 2g+1 (the last group has one tile + a dummy)
             const int s = p * 8 + 2 * g;                // ring position: 8 slots per pair (7 tiles + 1 dummy)
             {
                 const int sn = s + 2, pn = sn / 8, jn = sn % 8;
+#if W3_ABLATE == 2                                      // timing only: the U^T tiles of pair 0 again and again (L1 hits)
+                if (jn < TN) load_u(sn % RING, jn);
+                if (jn + 1 < TN) load_u((sn + 1) % RING, jn + 1);
+#elif W3_ABLATE == 3                                    // timing only: no U^T loads after the first two
+#else
                 if (jn < TN) load_u(sn % RING, pn * TN + jn);
                 if (jn + 1 < TN) load_u((sn + 1) % RING, pn * TN + jn + 1);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1041,7 +1062,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int j = 2 * g + jj;
-                        if (j < TN)
+                        if (j < TN && (W3_ABLATE != 4 || t == 0))     // 4: one product of six
                             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, ub[(s + jj) % RING][UT[t]]),
                                 __builtin_bit_cast(bf16x8, vs[i][VT[t]]), acc[j][i], 0, 0, 0);
@@ -1094,6 +1115,14 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
     if (gemm_bf16x3() && Ci == 216) {
         static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
         const int *Ub = reinterpret_cast<const int *>(U + (size_t)np * pad16(Ci) * W_BN);   // split copy behind U^T
+        static const int tm = [] { const char *e = getenv("DECNET_WINO_TM"); return e ? atoi(e) : 3; }();
+        if (tm == 6)        // one wave per SIMD, 96 tiles x 112 co per wave
+            hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7, 6>), dim3(ceil_div(nt, 192), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
+                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
+        else if (tm == 61)  // the same, two-wave workgroups (96 tiles x 224 co)
+            hipLaunchKernelGGL((wino_gemm_bf16x3<1, 7, 6>), dim3(ceil_div(nt, 96), np), dim3(128), 0, s, V, Ub, M, nt, Ci,
+                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
+        else
         hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(nt, 96), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
                            Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
         return decnet_launch_status();
