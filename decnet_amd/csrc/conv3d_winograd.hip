@@ -673,6 +673,89 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
 #endif
 }
 
+// ---- cost volume + input transform of the first layer (the cost volume never reaches HBM) ----
+// stage0.hip:costvol_cor_ndhwc computes cost[b,d,y,x,c] = (x >= d ? L[b,c,y,x] : 0) * bilinear(R[b,c]; x - d, y)
+// (GetCostVolume, submodule.py:479-522: warp_ope "homgrp", cost_func "cor") for decnet_costvol_forward; here the same
+// values -- the same fp32 operation sequence, fp contraction off -- are formed for one sample x four channels straight
+// into the LDS volume of wino_mid_transform, and that kernel's phase 2 writes their B^T transforms as V (quad major).
+// The bilinear coordinates depend on x - d and on y only: two small LDS tables (W + D and H entries).
+__global__ __launch_bounds__(MID_THREADS) void wino_head_transform(
+    const float *__restrict__ left, const float *__restrict__ right, float *__restrict__ V, Tiling g, int C, int nt) {
+#pragma clang fp contract(off)
+    extern __shared__ float ys[];                       // [D][H][4][Wp] | L [4][H][W] | R [4][H][W] | tables
+    constexpr int O = 4;
+    const int D = g.D, H = g.H, W = g.W, Wp = W | 1, vol = D * H * 4 * Wp, plane = H * W;
+    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;
+    const int b = blockIdx.x / nq, cq = blockIdx.x - b * nq;
+    const int nts = g.Td * g.Th * g.Tw, items = nts * 4;
+    const int xs = Q * nt * 16;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, 216 * xs, 0x00020000);
+    float *Ls = ys + vol, *Rs = Ls + 4 * plane;
+    float *tx = Rs + 4 * plane;                          // [W + D][3]: x0 (as float), wx0, wx1 of x - d = i - (D - 1)
+    float *ty = tx + 3 * (W + D);                        // [H][3]: y0, wy0, wy1
+    const int nch = C - cq * 4 < 4 ? C - cq * 4 : 4;
+    const size_t src = ((size_t)b * C + cq * 4) * plane; // the four channel planes are contiguous in NCHW
+    for (int i = threadIdx.x; i < 4 * plane; i += MID_THREADS) {
+        const bool ok = i < nch * plane;
+        Ls[i] = ok ? left[src + i] : 0.f;
+        Rs[i] = ok ? right[src + i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < W + D; i += MID_THREADS) {
+        const int xd = i - (D - 1);                      // x - d
+        const float cx = (float)xd / ((float)(W - 1.0) / 2.0f) - 1.0f;
+        const float ix = ((cx + 1.0f) * (float)W - 1.0f) / 2.0f;
+        const float fx = floorf(ix);
+        tx[3 * i] = fx; tx[3 * i + 2] = ix - fx; tx[3 * i + 1] = 1.0f - (ix - fx);
+    }
+    for (int y = threadIdx.x; y < H; y += MID_THREADS) {
+        const float cy = (float)y / ((float)(H - 1.0) / 2.0f) - 1.0f;
+        const float iy = ((cy + 1.0f) * (float)H - 1.0f) / 2.0f;
+        const float fy = floorf(iy);
+        ty[3 * y] = fy; ty[3 * y + 2] = iy - fy; ty[3 * y + 1] = 1.0f - (iy - fy);
+    }
+    __syncthreads();
+    // a thread owns (y, x, channel) positions and walks the disparities: the row part of the bilinear weights is
+    // fixed per position, the D iterations are independent (four in flight: the table look-ups and the taps are
+    // LDS round trips)
+    for (int e = threadIdx.x; e < 4 * plane; e += MID_THREADS) {
+        const int c = e & 3, yx = e >> 2, y = yx / W, x = yx - y * W;
+        const int y0 = (int)ty[3 * y], y1 = y0 + 1;
+        const float wy0 = ty[3 * y + 1], wy1 = ty[3 * y + 2];
+        const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+        const float *R0 = Rs + c * plane + (vy0 ? y0 : 0) * W, *R1 = Rs + c * plane + (vy1 ? y1 : 0) * W;
+        const float lv = Ls[c * plane + yx];
+        float *cell = ys + (y * 4 + c) * Wp + x;        // + d * H * 4 * Wp
+        const float *t0 = tx + 3 * (x + D - 1);         // - 3 d
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) {
+            const int x0 = (int)t0[-3 * d], x1 = x0 + 1;
+            const float wx0 = t0[-3 * d + 1], wx1 = t0[-3 * d + 2];
+            const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+            const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+            const float l = x >= d ? lv : 0.f;          // submodule.py:506-508
+            const float a00 = R0[vx0 ? x0 : 0], a01 = R0[vx1 ? x1 : 0], a10 = R1[vx0 ? x0 : 0], a11 = R1[vx1 ? x1 : 0];
+            float rr = 0.f;                             // same tap order as grid_sample
+            if (vy0 && vx0) rr += a00 * w00;
+            if (vy0 && vx1) rr += a01 * w01;
+            if (vy1 && vx0) rr += a10 * w10;
+            if (vy1 && vx1) rr += a11 * w11;
+            cell[d * H * 4 * Wp] = l * rr;              // submodule.py:521
+        }
+    }
+    __syncthreads();
+    const int itp = (items + 63) & ~63;
+    for (int it = threadIdx.x; it < 2 * itp; it += MID_THREADS) {
+        const int half = it >= itp, id = it - half * itp;
+        if (id >= items) continue;
+        const int ch = id & 3, tl = id >> 2;
+        int bb, z0, y0, x0;
+        tile_coords<O, O, O>(tl, g, bb, z0, y0, x0);
+        const int voff = ((cq * nt + b * nts + tl) * 4 + ch) * 4;
+        if (half == 0) mid_input_half<0>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
+        else mid_input_half<1>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
+    }
+}
+
 // ------------------------------ batched GEMM  M[xi] = V[xi] * U[xi] ----------------------
 // K = Ci is short (216), so an LDS-staged tile pipeline (the first version of this kernel: 192x224
 // tiles, double-buffered LDS as conv3d_k3_igemm) spent a quarter of its time filling and draining
@@ -958,7 +1041,7 @@ __global__ void wino_split_weights(const float *__restrict__ U, int *__restrict_
 }
 
 template <int WM, int NPAIR, int TM = 3>
-__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3 ? 1 : 2, TM > 3 ? 1 : 2))) void wino_gemm_bf16x3(
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3 ? 1 : TM == 2 ? 3 : 2, TM > 3 ? 1 : TM == 2 ? 3 : 2))) void wino_gemm_bf16x3(
     const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
     int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs) {
     // v_ms / v_kqs, m_ms / m_kqs: bytes between consecutive tiles and between the four 4-channel groups of a
@@ -1119,6 +1202,9 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
         if (tm == 6)        // one wave per SIMD, 96 tiles x 112 co per wave
             hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7, 6>), dim3(ceil_div(nt, 192), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
                                Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
+        else if (tm == 2)   // three waves per SIMD, 32 tiles x 112 co per wave
+            hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7, 2>), dim3(ceil_div(nt, 64), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
+                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
         else if (tm == 61)  // the same, two-wave workgroups (96 tiles x 224 co)
             hipLaunchKernelGGL((wino_gemm_bf16x3<1, 7, 6>), dim3(ceil_div(nt, 96), np), dim3(128), 0, s, V, Ub, M, nt, Ci,
                                Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
@@ -1197,7 +1283,14 @@ bool stack_ok(int B, int D, int H, int W, int C, int variant) {
     return (double)T * pad16(C) * 4 * 216 < 2147483647.0 && (double)B * D * H * W * C * 4 < 2147483647.0;
 }
 
-int conv_stack(const float *x, const float *const *u, const float *const *scale, const float *const *shift,
+size_t head_lds_bytes(int D, int H, int W) {
+    return stack_lds_bytes(D, H, W) + ((size_t)8 * H * W + 3 * (W + D) + 3 * H) * 4;
+}
+
+// x != nullptr: the stack's input is a channels-last volume; x == nullptr: it is the cost volume of (left, right),
+// formed on chip by wino_head_transform
+int conv_stack(const float *x, const float *left, const float *right, const float *const *u,
+               const float *const *scale, const float *const *shift,
                int n_layers, int res_src, int res_dst, float *y, float *workspace, float *R, int B, int D, int H,
                int W, int C, hipStream_t s) {
     constexpr int NP = 216;
@@ -1214,16 +1307,30 @@ int conv_stack(const float *x, const float *const *u, const float *const *scale,
         }
         lds_set = lds;
     }
-    const int ith = C >= 256 ? 256 : (C + 63) / 64 * 64;
-    hipLaunchKernelGGL((wino_input_transform<6, 6, 6, 1>), dim3((unsigned)(8 * ((nt + 7) / 8)), (unsigned)ceil_div(C, ith)),
-                       dim3(ith), 0, s, x, V, g, C, 0, nt, bytes);
+    if (x) {
+        const int ith = C >= 256 ? 256 : (C + 63) / 64 * 64;
+        hipLaunchKernelGGL((wino_input_transform<6, 6, 6, 1>), dim3((unsigned)(8 * ((nt + 7) / 8)), (unsigned)ceil_div(C, ith)),
+                           dim3(ith), 0, s, x, V, g, C, 0, nt, bytes);
+    } else {
+        const size_t hl = head_lds_bytes(D, H, W);
+        static size_t hl_set = 0;
+        if (hl > hl_set) {
+            if (hipFuncSetAttribute((const void *)wino_head_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl) != hipSuccess) {
+                (void)hipGetLastError();
+                return DECNET_ERR_UNSUPPORTED;
+            }
+            hl_set = hl;
+        }
+        hipLaunchKernelGGL(wino_head_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), hl, s, left, right, V,
+                           g, C, nt);
+    }
     int rc = decnet_launch_status();
     if (rc) return rc;
     for (int i = 0; i < n_layers; ++i) {
         const bool last = i == n_layers - 1;
         // V of layer 0 comes from wino_input_transform (chunk major), M of the last layer goes to
         // wino_output_transform (chunk major); everything between is quad major
-        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0, !last))) return rc;
+        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0 || !x, !last))) return rc;
         if (last) {
             const size_t n = (size_t)nt * pad16(C);
             hipLaunchKernelGGL((wino_output_transform<6, 6, 6, 1>), dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, s,
@@ -1338,8 +1445,29 @@ int decnet_conv3d_wino_stack_bn_act(const float *x, const float *const *u, const
     if (res_src >= 0 && !(res_src < res_dst && res_dst < n_layers - 1)) return DECNET_ERR_UNSUPPORTED;
     if (n_layers < 2 || !stack_ok(B, D, H, W, C, variant)) return DECNET_ERR_UNSUPPORTED;
     const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
-    return conv_stack(x, u, scale, shift, n_layers, res_src, res_dst, y, workspace, workspace + w, B, D, H, W, C,
-                      (hipStream_t)stream);
+    return conv_stack(x, nullptr, nullptr, u, scale, shift, n_layers, res_src, res_dst, y, workspace, workspace + w, B, D, H,
+                      W, C, (hipStream_t)stream);
+}
+
+/* The same stack fed by the stage-0 cost volume of (left, right) [B,C,H,W] (decnet_costvol_forward's values, D
+ * disparities) without writing that volume: its input transform is formed on chip.  Same workspace; additionally needs
+ * H, W >= 2 and the two feature planes of four channels next to the volume in LDS (DECNET_ERR_UNSUPPORTED otherwise). */
+int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, const float *const *u,
+                                     const float *const *scale, const float *const *shift, int n_layers, int res_src,
+                                     int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
+                                     int variant, void *stream) {
+    if (!left || !right || !u || !scale || !shift || !y || !workspace) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || D < 1 || H < 2 || W < 2 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    for (int i = 0; i < n_layers; ++i)
+        if (!u[i] || !scale[i] || !shift[i]) return DECNET_ERR_NULL_POINTER;
+    if ((res_src < 0) != (res_dst < 0)) return DECNET_ERR_BAD_SHAPE;
+    if (res_src >= 0 && !(res_src < res_dst && res_dst < n_layers - 1)) return DECNET_ERR_UNSUPPORTED;
+    static const int off = [] { const char *e = getenv("DECNET_WINO_HEAD"); return e && !strcmp(e, "0") ? 1 : 0; }();
+    if (off || n_layers < 2 || !stack_ok(B, D, H, W, C, variant) || head_lds_bytes(D, H, W) > 160 * 1024)
+        return DECNET_ERR_UNSUPPORTED;
+    const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
+    return conv_stack(nullptr, left, right, u, scale, shift, n_layers, res_src, res_dst, y, workspace, workspace + w, B, D, H,
+                      W, C, (hipStream_t)stream);
 }
 
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale, const float *shift,

@@ -51,8 +51,19 @@ int decnet_stage0_forward(const float *left, const float *right, const decnet_st
     const size_t last = decnet_conv3d_cout1_workspace_floats(B, D, H, W);
     float *t_last = last > act ? ws + wino : a;
 
-    int rc = decnet_costvol_forward(left, right, cv, B, C, H, W, D, stream);
-    if (rc) return rc;
+    int rc = DECNET_ERR_UNSUPPORTED;
+    if (stack)      // cost volume + all seven layers, neither the volume nor the activations between the layers in HBM
+        rc = decnet_costvol_wino_stack_bn_act(left, right, p->w, p->scale, p->shift, 7, 1, 4, c, ws, B, C, H, W, D, variant,
+                                              stream);
+    if (rc == DECNET_OK) {
+        if (C <= 256 && D <= 256)
+            return decnet_conv3d_cout1_softargmax_ws(c, p->w_last, p->scale_last, p->shift_last, reg, pred, t_last, B,
+                                                     D, H, W, C, stream);
+        return decnet_conv3d_cout1_softargmax(c, p->w_last, p->scale_last, p->shift_last, reg, pred, B, D, H, W, C,
+                                              stream);
+    }
+    if (rc != DECNET_ERR_UNSUPPORTED) return rc;
+    if ((rc = decnet_costvol_forward(left, right, cv, B, C, H, W, D, stream))) return rc;
     auto conv = [&](int i, const float *src, float *dst, const float *res) {
         if (variant <= 2)
             return decnet_conv3d_wino_bn_act(src, p->w[i], p->scale[i], p->shift[i], res, dst, ws, B, D, H, W, C, C,

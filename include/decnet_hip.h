@@ -166,6 +166,14 @@ size_t decnet_conv3d_wino_stack_workspace_floats(int B, int D, int H, int W, int
 int decnet_conv3d_wino_stack_bn_act(const float *x, const float *const *u, const float *const *scale,
                                     const float *const *shift, int n_layers, int res_src, int res_dst, float *y,
                                     float *workspace, int B, int D, int H, int W, int C, int variant, void *stream);
+/* The same stack fed by the stage-0 cost volume of (left, right) [B,C,H,W] -- the values decnet_costvol_forward writes
+ * (GetCostVolume, submodule.py:479-522), D disparity planes -- without that volume ever reaching HBM: the first layer's
+ * input transform is formed on chip from the two feature maps.  Workspace as above.  DECNET_ERR_UNSUPPORTED (nothing
+ * launched) where decnet_conv3d_wino_stack_bn_act is, or when the feature planes do not fit in LDS beside the volume. */
+int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, const float *const *u,
+                                     const float *const *scale, const float *const *shift, int n_layers, int res_src,
+                                     int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
+                                     int variant, void *stream);
 
 /* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
  * over disp_samples = arange(D) (submodule.py:766-777):

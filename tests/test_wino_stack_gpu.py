@@ -156,3 +156,28 @@ def test_module_uses_the_stack_and_agrees_with_the_unfused_path(dev):
             os.environ["DECNET_WINO_STACK"] = old
     assert float((r0 - r1).abs().max()) <= 1e-5 * max(1.0, float(r0.abs().max()))
     assert float((p0 - p1).abs().max()) <= 1e-3       # random weights: a nearly flat volume under the soft-argmax
+
+
+@pytest.mark.parametrize("B,H,W,D", [(2, 20, 36, 8), (1, 7, 10, 6), (1, 5, 9, 3)])
+def test_cost_volume_formed_on_chip(dev, B, H, W, D):
+    """decnet_costvol_wino_stack_bn_act (left, right -> stack) against decnet_costvol_forward + the stack on that volume."""
+    from decnet_amd import _lib
+    L = _lib.lib()
+    C, n = 216, 3
+    layers = _layers(n, C, dev, seed=11)
+    g = torch.Generator().manual_seed(3)
+    left = torch.randn(B, C, H, W, generator=g).to(dev)
+    right = torch.randn(B, C, H, W, generator=g).to(dev)
+    cv = torch.empty(B, D, H, W, C, device=dev)
+    _lib.check(L.decnet_costvol_forward(left.data_ptr(), right.data_ptr(), cv.data_ptr(), B, C, H, W, D, None), "costvol")
+    ref = _stack(layers, cv, 0, 1)
+    ws = torch.empty(L.decnet_conv3d_wino_stack_workspace_floats(B, D, H, W, C, 2), dtype=torch.float32, device=dev)
+    y = torch.full_like(cv, float("nan"))
+    arr = ctypes.c_void_p * n
+    u, sc, sh = (arr(*[p[k].data_ptr() for p in layers]) for k in ("u", "scale", "shift"))
+    _lib.check(L.decnet_costvol_wino_stack_bn_act(left.data_ptr(), right.data_ptr(), u, sc, sh, n, 0, 1, y.data_ptr(),
+                                                  ws.data_ptr(), B, C, H, W, D, 2, None), "costvol stack")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    err = float((y - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
