@@ -1131,6 +1131,8 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3
 #if W3_ABLATE == 2                                      // timing only: the U^T tiles of pair 0 again and again (L1 hits)
                 if (jn < TN) load_u(sn % RING, jn);
                 if (jn + 1 < TN) load_u((sn + 1) % RING, jn + 1);
+#elif W3_ABLATE == 5                                    // timing only: every other U^T tile loaded (half the requests)
+                if (jn < TN) load_u(sn % RING, pn * TN + jn);
 #elif W3_ABLATE == 3                                    // timing only: no U^T loads after the first two
 #else
                 if (jn < TN) load_u(sn % RING, pn * TN + jn);
@@ -1151,6 +1153,136 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3
                                 __builtin_bit_cast(bf16x8, vs[i][VT[t]]), acc[j][i], 0, 0, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int pb = pt * m_point + kq * m_kqs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cg = wn * TN + j;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 a = acc[j][i];
+            __builtin_amdgcn_raw_buffer_store_b128(
+                i32x4{__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])},
+                mr, cg < CG && m_row[i] != OOB ? m_row[i] + pb + cg * v_chunk : OOB, 0, 0);
+        }
+    }
+}
+
+// The same product with the U^T terms shared through LDS.  tools: W3_ABLATE builds of the kernel above show what it
+// waits for -- not HBM and not the V split, but the number of operand REQUESTS per CU: with the U^T tiles always hitting
+// in L2 the time is unchanged (0.112 ms), with every other U^T tile load removed it is 0.090 ms, with none 0.060 ms.  In
+// the kernel above each U^T tile of a (point, k pair) is fetched by every wave that needs it (2 of the 4 waves of a
+// workgroup, all 8 row blocks).  Here a workgroup is 8 waves = 192 tiles x 224 co: the 42 KB of U^T terms of a k pair
+// come into LDS ONCE per workgroup by LDS-DMA (buffer_load ... lds, 16 bytes per lane: a wave-instruction moves the
+// 1 KB operand block of one (term, 16 co) so that every lane later reads ITS 16 bytes back with one ds_read_b128),
+// double buffered, one barrier per k pair; V stays register-direct.  Requests per 32 k and workgroup: 42 + 48 instead
+// of 2 x (84 + 24) for the same rows.
+#define LDS_PTR3(p) ((__attribute__((address_space(3))) void *)(p))
+template <int NPAIR>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_bf16x3_lds(
+    const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
+    int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs) {
+    constexpr int TM = 3, TN = 7, OOB = 0x7fffffff, RING = 4, UBUF = 3 * 14 * 256;   // ints per LDS buffer (42 KB)
+    extern __shared__ __attribute__((aligned(16))) int ulds[];                       // [2][term][16-co tile][lane][4]
+    const int mblocks = gridDim.x, ngroups = gridDim.y;
+    int pt = blockIdx.y, mb = blockIdx.x;
+    if (swz) {
+        const int id = blockIdx.y * mblocks + blockIdx.x, per8 = 8 * mblocks;
+        const int r = id / per8, q = id - r * per8;
+        if (8 * (r + 1) <= ngroups) { pt = 8 * r + (q & 7); mb = q >> 3; }
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, kq = lane >> 4;
+    const int m0 = (mb * 4 + wm) * 48;                 // (waves past the last tile keep running on out-of-range rows:
+    const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;    // they take part in the copies and the barriers)
+    const int v_chunk = nt * 64, v_point = KC * v_chunk, m_point = CG * v_chunk;
+    const int u_term = W_BN * 64, u_pair = 3 * u_term, u_point = NPAIR * u_pair;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * v_point, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ubb, 0, np * u_point, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * m_point, 0x00020000);
+    int v_row[TM], m_row[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + i * 16 + i16;
+        v_row[i] = m < nt ? m * v_ms : OOB;
+        m_row[i] = m < nt ? m * m_ms : OOB;
+    }
+    // copy q of a k pair = (term q / 14, 16-co tile q % 14): the lane's source is where it would load the operand from
+    const int u_src = i16 * 64 + kq * 16 + pt * u_point;
+    auto dma = [&](int p, int buf) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int q = wave + 8 * k;
+            if (q < 42) {
+                const int term = q / 14, jt = q - term * 14;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, LDS_PTR3(ulds + buf * UBUF + q * 256), 16,
+                                                         p < NPAIR ? u_src + p * u_pair + term * u_term + jt * 1024 : OOB, 0, 0, 0);
+            }
+        }
+    };
+    f32x4 vf[TM][2];
+    i32x4 ub[RING][3], vs[TM][3];
+    auto read_u = [&](int slot, int buf, int j) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+            ub[slot][term] = *reinterpret_cast<const i32x4 *>(ulds + buf * UBUF + (term * 14 + wn * TN + j) * 256 + lane * 4);
+    };
+    auto load_v = [&](int p) {
+        const int vb = pt * v_point + kq * v_kqs;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = 2 * p + h;
+                const bool ok = p < NPAIR && v_row[i] != OOB && c * 16 + kq * 4 < Ci;
+                const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(vr, ok ? v_row[i] + vb + c * v_chunk : OOB, 0, 0);
+                vf[i][h] = f32x4{__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w)};
+            }
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UT[6] = {2, 1, 0, 1, 0, 0}, VT[6] = {0, 1, 2, 0, 1, 0};
+
+    dma(0, 0);
+    load_v(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+        const int buf = p & 1;
+        if (p + 1 < NPAIR) dma(p + 1, buf ^ 1);         // the other buffer was last read before the previous barrier
+#pragma unroll
+        for (int i = 0; i < TM; ++i) split3(vf[i][0], vf[i][1], vs[i][0], vs[i][1], vs[i][2]);
+        load_v(p + 1);
+        read_u(0, buf, 0);
+        read_u(1, buf, 1);
+#pragma unroll
+        for (int g = 0; g < (TN + 1) / 2; ++g) {
+            const int j0 = 2 * g;
+            if (j0 + 2 < TN) read_u((j0 + 2) % RING, buf, j0 + 2);
+            if (j0 + 3 < TN) read_u((j0 + 3) % RING, buf, j0 + 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int j = j0 + jj;
+                        if (j < TN)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, ub[j % RING][UT[t]]),
+                                __builtin_bit_cast(bf16x8, vs[i][VT[t]]), acc[j][i], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (p + 1 < NPAIR) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of pair p + 1 (and its V) have landed
+            __syncthreads();                                     // ... everybody's have, and nobody reads this buffer any more
         }
     }
     const int pb = pt * m_point + kq * m_kqs;
@@ -1199,6 +1331,21 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
         static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
         const int *Ub = reinterpret_cast<const int *>(U + (size_t)np * pad16(Ci) * W_BN);   // split copy behind U^T
         static const int tm = [] { const char *e = getenv("DECNET_WINO_TM"); return e ? atoi(e) : 3; }();
+        static const int use_lds = [] { const char *e = getenv("DECNET_WINO_GEMM_LDS"); return e ? atoi(e) : 0; }();
+        if (use_lds && tm == 3) {
+            constexpr int lds = 2 * 3 * 14 * 1024;
+            static int lds_set = 0;
+            if (!lds_set) {
+                if (hipFuncSetAttribute((const void *)wino_gemm_bf16x3_lds<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return DECNET_ERR_UNSUPPORTED;
+                }
+                lds_set = 1;
+            }
+            hipLaunchKernelGGL((wino_gemm_bf16x3_lds<7>), dim3(ceil_div(nt, 192), np), dim3(512), lds, s, V, Ub, M, nt, Ci,
+                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
+            return decnet_launch_status();
+        }
         if (tm == 6)        // one wave per SIMD, 96 tiles x 112 co per wave
             hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7, 6>), dim3(ceil_div(nt, 192), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
                                Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
