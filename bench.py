@@ -710,9 +710,26 @@ def main():
                 wsp = torch.empty(L.decnet_conv3d_wino_workspace_floats(B, D0, H0, W0, C0, C0, var), device=dev)
                 cp = (C0 + 15) // 16 * 16
                 V, Mw = wsp[:npts * nt * cp], wsp[npts * nt * cp:]
-                layer_ms = time_kernel(lambda: L.decnet_conv3d_wino_bn_act(
+                # (the step forms the cost volume on chip where the fused stack covers the shape: write it out for
+                # the per-layer timings below)
+                Lf0, Rf0 = hp.feats[0]
+                _lib.check(L.decnet_costvol_forward(Lf0.data_ptr(), Rf0.data_ptr(), cv.data_ptr(), B, C0, H0, W0, D0, st),
+                           "decnet_costvol_forward")
+                layer_unfused_ms = layer_ms = time_kernel(lambda: L.decnet_conv3d_wino_bn_act(
                     cv.data_ptr(), p0["u"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr(), None,
                     a.data_ptr(), wsp.data_ptr(), B, D0, H0, W0, C0, C0, 1, var, st), 30)
+                # the seven C -> C layers as the step runs them: one fused stack (output transform of layer i and input
+                # transform of layer i + 1 in one kernel, activations between the layers in LDS)
+                stack_ms = None
+                nst = L.decnet_conv3d_wino_stack_workspace_floats(B, D0, H0, W0, C0, var)
+                if nst and os.environ.get("DECNET_WINO_STACK", "1") != "0":
+                    import ctypes
+                    wst = torch.empty(nst, device=dev)
+                    arr = ctypes.c_void_p * 7
+                    us, scs, shs = (arr(*[P[i][k].data_ptr() for i in range(7)]) for k in ("u", "scale", "shift"))
+                    stack_ms = time_kernel(lambda: L.decnet_conv3d_wino_stack_bn_act(
+                        cv.data_ptr(), us, scs, shs, 7, 1, 4, a.data_ptr(), wst.data_ptr(), B, D0, H0, W0, C0, var, st), 20)
+                    layer_ms = stack_ms / 7.0
                 conv_ms = time_kernel(lambda: L.decnet_conv3d_wino_gemm(
                     V.data_ptr(), p0["u"].data_ptr(), Mw.data_ptr(), nt, C0, C0, var, st), 60)
                 kern_flop = 2.0 * npts * nt * C0 * C0
@@ -726,6 +743,7 @@ def main():
                     ("Winograd F(2,3)^3", "Winograd F(2,3)xF(4,3)^2", "Winograd F(4,3)^3")[var])
                 tkey = "wino_gemm"
             else:
+                stack_ms = layer_unfused_ms = None
                 conv_ms = layer_ms = time_kernel(lambda: L.decnet_conv3d_bn_act(
                     cv.data_ptr(), p0["w"].data_ptr(), p0["scale"].data_ptr(), p0["shift"].data_ptr(), None,
                     a.data_ptr(), B, D0, H0, W0, C0, C0, 1, st), 10)
@@ -807,7 +825,10 @@ def main():
                          "fp32_equivalent_tflops": kern_flop / conv_ms / 1e9,
                          "fp32_equivalent_frac_of_fp32_mfma_peak": kern_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
                          "arithmetic": gemm_arith, "stage0_ms_in_step": s0_ms,
-                         "conv3d_layer_ms": layer_ms,
+                         # one of the seven 216 -> 216 layers: a seventh of the fused stack where the step runs it
+                         # (conv3d_stack_ms), else one decnet_conv3d_wino_bn_act call (= conv3d_layer_unfused_ms)
+                         "conv3d_layer_ms": layer_ms, "conv3d_stack_ms": stack_ms,
+                         "conv3d_layer_unfused_ms": layer_unfused_ms,
                          "conv3d_layer_direct_equiv_tflops": conv_flop / layer_ms / 1e9},
             "roofline_costvol": {"bound": "hbm", "achieved": s3_bytes / s3_ms / 1e6, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": s3_bytes / s3_ms / 1e6 / HBM_PEAK_GBS,

@@ -17,6 +17,8 @@ KEYS = {                                    # substring of the kernel name -> ke
     "wino_gemm_persist<": "wino_gemm",
     "wino_gemm_bf16x3": "wino_gemm",
     "wino_gemm<": "wino_gemm",
+    "wino_mid_transform": "wino_mid_transform",
+    "wino_head_transform": "wino_head_transform",
     "wino_input_transform": "wino_input_transform",
     "wino_output_transform": "wino_output_transform",
     "conv3d_k3_igemm": "conv3d_k3_igemm",
