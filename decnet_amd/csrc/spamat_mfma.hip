@@ -472,7 +472,7 @@ __device__ __forceinline__ int sparse_row_body(
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
     int H, int W, int D, int row, int dense_pct, int mbits);
-constexpr int MID_CAP = 512;                            // active pixels per side of a "mid-density" row (marker == 2)
+constexpr int MID_CAP = 512;                            // active pixels per side of a "mid-density" row (-2 marker): 42 KB of LDS
 
 template <int NT, int MODE, int KQ, bool D16>
 __device__ __forceinline__ void spamat_fwd_segment(
@@ -976,47 +976,54 @@ __device__ __forceinline__ int sparse_row_body(
     __syncthreads();
 
     // ---- 2. features of the active pixels (loads first, LDS stores after the span selection)
-    float rf[CQ], lf[CQ];
-    const int xr_own = tid < nR ? XR[tid] : -1, xl_own = tid < nL ? XL[tid] : -1;
+    constexpr int SPT = (CAP + NTHR - 1) / NTHR;       // slots per thread (1, or 2 for the 256-thread mid-density kernel)
+    float rf[SPT][CQ], lf[SPT][CQ];
 #pragma unroll
-    for (int c = 0; c < CQ; ++c) {
-        rf[c] = (xr_own >= 0 && c < C) ? rrow[(size_t)c * plane + xr_own] : 0.f;
-        lf[c] = (xl_own >= 0 && c < C) ? lrow[(size_t)c * plane + xl_own] : 0.f;
-    }
-    // span: a power-of-two number of pixels holding <= ~16 active left pixels whose disparity
-    // window holds at most 16*NTC - 15 active right pixels everywhere
-    int S = 128;
-    while (S > 16 && (long)S * nL > 24L * W) S >>= 1;
-    for (;;) {
-        int bad = 0;
-        for (int g = tid; g * S < W; g += NTHR) {
-            const int jlo = max(0, g * S - (D - 1)), jhi = min(W - 1, g * S + S - 1);
-            if ((int)RK[jhi + 1] - (int)RK[jlo] > 16 * NTC - 15) bad = 1;
+    for (int u = 0; u < SPT; ++u) {
+        const int slot = tid + u * NTHR;
+        const int xr_own = slot < nR ? XR[slot] : -1, xl_own = slot < nL ? XL[slot] : -1;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            rf[u][c] = (xr_own >= 0 && c < C) ? rrow[(size_t)c * plane + xr_own] : 0.f;
+            lf[u][c] = (xl_own >= 0 && c < C) ? lrow[(size_t)c * plane + xl_own] : 0.f;
         }
-        if (!__syncthreads_or(bad)) break;
-        if (S == 16) return 2;                          // nothing written yet; more tiles per span may do
-        S >>= 1;
+    }
+    // chunks of 16 consecutive ACTIVE left pixels (whatever their positions): the window of a chunk is every active
+    // right pixel one of them can match, [x_first - (D - 1), x_last]; it has to fit NTC tiles.  (Round 2 cut the row
+    // into spans of a power-of-two number of pixels and chunked inside a span: at density 0.3 that is 30 chunks of
+    // 9.6 active pixels on average instead of 19 full ones, and a search loop of block-wide votes for the span size.)
+    const int nchunk = (nL + 15) >> 4;
+    {
+        int bad = 0;
+        for (int k = tid; k < nchunk; k += NTHR) {
+            const int xa = XL[16 * k], xb = XL[min(16 * k + 15, nL - 1)];
+            if ((int)RK[xb + 1] - (int)RK[max(0, xa - (D - 1))] > 16 * NTC - 15) bad = 1;
+        }
+        if (__syncthreads_or(bad)) return 2;            // nothing written yet; more tiles per chunk may do
     }
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {
-        RF[c * SP_FP_ + tid] = rf[c];                    // slots >= nR hold zeros
-        LF[c * SP_FP_ + tid] = lf[c];
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const int slot = tid + u * NTHR;
+            if (slot < CAP) {
+                RF[c * SP_FP_ + slot] = rf[u][c];        // slots >= nR hold zeros
+                LF[c * SP_FP_ + slot] = lf[u][c];
+            }
+        }
         if (tid < 16) RF[c * SP_FP_ + CAP + tid] = 0.f;
     }
     __syncthreads();
 
     // ---- 3. matching
     const int j = lane & 15, q = lane >> 4;
-    const int ngroups = (W + S - 1) / S;
-    for (int g = wave; g < ngroups; g += SP_NWAVE_) {
-        const int gx = g * S;
-        const int e0 = RKL[gx], e1 = RKL[min(gx + S, W)];
-        if (e1 == e0) continue;
-        const int jlo = max(0, gx - (D - 1)), jhi = min(W - 1, gx + S - 1);
-        const int r_lo = RK[jlo], r_hi = RK[jhi + 1];
-        const int t0 = r_lo >> 4;
-        const int ntile = r_hi > r_lo ? ((r_hi - 1) >> 4) - t0 + 1 : 0;      // <= NTC
-        for (int e = e0; e < e1; e += 16) {
+    for (int k = wave; k < nchunk; k += SP_NWAVE_) {
+        const int e1 = nL;
+        for (int e = 16 * k; e < min(16 * k + 16, nL); e += 16) {      // (one trip: the loop shape the register allocator
+            const int xa = XL[e], xb = XL[min(e + 15, nL - 1)];       //  handled without spilling)
+            const int r_lo = RK[max(0, xa - (D - 1))], r_hi = RK[xb + 1];
+            const int t0 = r_lo >> 4;
+            const int ntile = r_hi > r_lo ? ((r_hi - 1) >> 4) - t0 + 1 : 0;      // <= NTC
             const bool act = e + j < e1;
             const int el = act ? e + j : e1 - 1;
             const int xl = XL[el];
@@ -1111,6 +1118,27 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     }
 }
 
+// Rows the kernel above handed over with -2 (257 .. MID_CAP active pixels per side: densities 0.25 - 0.5 at stage 3): the
+// same body with MID_CAP slots and NT + 1 tiles per chunk on 256 threads -- 42 KB of LDS, three rows per CU in flight, where
+// the band kernel's own 512-thread workgroup (marker == 2, the default) holds two.  Opt-in (DECNET_SPAMAT_MID=1): the extra
+// launch and the halved threads per row cost more than the occupancy gives.  A row this body does not take either is
+// re-marked -1 for the band kernel.
+template <int NT, int MODE, int KQ, int PPT>
+__global__ __launch_bounds__(SP_THREADS, 4) void spamat_fwd_sparse_mid(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
+    float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
+    int H, int W, int D, int seg_w, int dense_pct, int mbits) {
+    const int row = blockIdx.x;
+    const size_t rowpix = (size_t)row * W;
+    if (sum_sim[rowpix] != -2.0f) return;
+    const int rc = sparse_row_body<NT, MODE, KQ, PPT, SP_THREADS, MID_CAP, NT + 1>(ref, tar, rmask, tmask, disparity, out,
+                                                                                  var_out, sum_sim, max_cost, C, H, W, D, row,
+                                                                                  dense_pct, mbits);
+    if (rc != 1)
+        for (int x = threadIdx.x * seg_w; x < W; x += SP_THREADS * seg_w) sum_sim[rowpix + x] = -1.0f;
+}
+
 template <int NT, int KQ>
 int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
@@ -1154,9 +1182,15 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     int marker = allow_compact && !sparse_off && (KQ == 2 || (KQ == 6 && sparse_c24)) && W <= 2048;
     // rows of 257-512 active pixels per side: the sparse-row algorithm inside the band kernel's workgroup (whole rows
     // per workgroup only; DECNET_SPAMAT_MID=0 switches it off)
-    static const int mid_off = [] { const char *e = getenv("DECNET_SPAMAT_MID"); return e && atoi(e) == 0; }();
+    // DECNET_SPAMAT_MID: 0 off | 2 (default) inside the band kernel's workgroup (512 threads, two rows per CU) |
+    // 1 their own 256-thread launch between the two (spamat_fwd_sparse_mid: three rows per CU, one more launch;
+    // measured 0.169 vs 0.152 ms at density 0.3, 0.316 vs 0.268 at 0.5)
+    static const int mid_mode = [] { const char *e = getenv("DECNET_SPAMAT_MID"); return e ? atoi(e) : 2; }();
+    const bool mid_off = mid_mode == 0;
+    const bool mid_own = mid_mode == 1 && KQ == 2 && marker && segs == 1 && W <= 1024 &&
+                         4 * sparse_row_words(2, 4, SP_THREADS, MID_CAP) <= DECNET_LDS_BYTES - 1024;
     size_t lds_launch = lds;
-    if (KQ == 2 && marker && segs == 1 && !mid_off) {
+    if (KQ == 2 && marker && segs == 1 && !mid_off && !mid_own) {
         const size_t need = 4 * sparse_row_words(KQ, 4, THREADS, MID_CAP);
         if (need <= budget2 + 8192) {
             marker = 2;
@@ -1187,8 +1221,29 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         else LAUNCHSP(MODE_FUSED);
 #undef LAUNCHSP
 #undef LAUNCHS
-        const int rc = decnet_launch_status();
+        int rc = decnet_launch_status();
         if (rc) return rc;
+        if constexpr (KQ == 2) if (mid_own) {
+            const size_t mlds = 4 * sparse_row_words(2, 4, SP_THREADS, MID_CAP);
+#define LAUNCHM(M)                                                                                 \
+    do {                                                                                           \
+        static bool set_##M = false;                                                               \
+        if (!set_##M) {                                                                            \
+            hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_sparse_mid<NT, M, 2, 4>,   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); \
+            if (e != hipSuccess) return (int)e;                                                    \
+            set_##M = true;                                                                        \
+        }                                                                                          \
+        hipLaunchKernelGGL((spamat_fwd_sparse_mid<NT, M, 2, 4>), dim3((unsigned)(B * H)), dim3(SP_THREADS), mlds, stream, \
+                           ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, XT * 16, \
+                           compact_pct, mbits);                                                    \
+    } while (0)
+            if (mode == MODE_MAT) LAUNCHM(MODE_MAT);
+            else if (mode == MODE_VAR) LAUNCHM(MODE_VAR);
+            else LAUNCHM(MODE_FUSED);
+#undef LAUNCHM
+            if ((rc = decnet_launch_status())) return rc;
+        }
     }
 #define LAUNCH1(M, DD)                                                                             \
     do {                                                                                           \
