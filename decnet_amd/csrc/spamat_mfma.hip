@@ -472,7 +472,7 @@ __device__ __forceinline__ int sparse_row_body(
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
     int H, int W, int D, int row, int dense_pct, int mbits);
-constexpr int MID_CAP = 512;                            // active pixels per side of a "mid-density" row (-2 marker): 42 KB of LDS
+constexpr int MID_CAP = 640;                            // active pixels per side of a "mid-density" row (-2 marker): 55 KB of LDS
 
 template <int NT, int MODE, int KQ, bool D16>
 __device__ __forceinline__ void spamat_fwd_segment(
@@ -492,8 +492,8 @@ __device__ __forceinline__ void spamat_fwd_segment(
         // with 512 slots and NT + 1 tiles, instead of the compact path below
         if (marker == 2 && mark == -2.0f) {
             if (sparse_row_body<NT, MODE, KQ, 4, THREADS, MID_CAP, NT + 1>(ref, tar, rmask, tmask, disparity, out, var_out,
-                                                                          sum_sim, max_cost, C, H, W, D, row, compact_pct,
-                                                                          mbits) == 1)
+                                                                          sum_sim, max_cost, C, H, W, D, row, 100,
+                                                                          mbits) == 1)      // (the -2 marker means the sparse-row kernel's density test passed)
                 return;
             __syncthreads();                            // its LDS arrays are free again
         }
@@ -1173,6 +1173,10 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     // rows go through the compaction path when fewer than compact_pct % of their candidate pairs are active
     // (DECNET_SPAMAT_COMPACT_PCT; 80 in round 1 -- but the dense path is faster down to ~35 %, measured)
     static const int compact_pct = [] { const char *e = getenv("DECNET_SPAMAT_COMPACT_PCT"); return e ? atoi(e) : 35; }();
+    // ... and through the sparse-row algorithm (spamat_fwd_sparse, and the MID_CAP-slot body behind its -2 marker) below
+    // sparse_pct %: with chunks of 16 active pixels that algorithm beats the dense path up to ~45 % (stage 3, density
+    // 0.6 = 36 % of the pairs: 0.30 vs 0.42 ms; DECNET_SPAMAT_SPARSE_PCT)
+    static const int sparse_pct = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE_PCT"); return e ? atoi(e) : 45; }();
     dim3 grid((unsigned)((size_t)B * H * segs));
     // sparse rows first (KQ > 0: C <= 24; rows of <= 2048 pixels), the rest by the marker launch
     static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
@@ -1209,7 +1213,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_sparse<NT, M, (KQ ? KQ : 1), P>), dim3((unsigned)(B * H)),  \
                            dim3(SP_THREADS), slds, stream, ref, tar, rmask, tmask, disparity, out, \
-                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16, compact_pct, mbits);   \
+                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16, sparse_pct, mbits);    \
     } while (0)
 #define LAUNCHSP(M)                                                                                \
     do {                                                                                           \
@@ -1236,7 +1240,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_sparse_mid<NT, M, 2, 4>), dim3((unsigned)(B * H)), dim3(SP_THREADS), mlds, stream, \
                            ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, XT * 16, \
-                           compact_pct, mbits);                                                    \
+                           sparse_pct, mbits);                                                     \
     } while (0)
             if (mode == MODE_MAT) LAUNCHM(MODE_MAT);
             else if (mode == MODE_VAR) LAUNCHM(MODE_VAR);
