@@ -547,29 +547,14 @@ __device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __a
     }
 }
 
-__global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
-    const float *__restrict__ M, float *__restrict__ V, const float *__restrict__ scale,
-    const float *__restrict__ shift, const float *__restrict__ res_in, float *__restrict__ res_out, Tiling g,
-    int C, int nt, int relu) {
-    extern __shared__ float ys[];                       // [D][H][4][Wp]
+// Phase 1 of wino_mid_transform / wino_tail_transform: the sample's M tiles of four channels -> y = relu(A^T M A * scale +
+// shift) (+ what the LDS volume held before: the preloaded residual) into the LDS volume [D][H][4][Wp].  A^T along W and H
+// per depth plane of M, the D pass as an accumulation; one thread per (tile, channel), two planes of M in flight.
+__device__ __forceinline__ void wino_output_phase(__amdgpu_buffer_rsrc_t mr, float *__restrict__ ys, const Tiling &g, int Wp,
+                                                  int cq, int b, int nts, int nt, int xs, const float *__restrict__ scale,
+                                                  const float *__restrict__ shift, int C, int relu, bool res_in) {
     constexpr int T = 6, O = 4;
-    const int Wp = g.W | 1, vol = g.D * g.H * 4 * Wp;
-    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;     // quads with data, quads per transform point
-    const int b = blockIdx.x / nq, cq = blockIdx.x - b * nq;
-    const int nts = g.Td * g.Th * g.Tw, items = nts * 4;
-    const int xs = Q * nt * 16;                         // bytes between transform points
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, 216 * xs, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, 216 * xs, 0x00020000);
-    const size_t blk = ((size_t)b * nq + cq) * vol;     // this workgroup's block of R
-    if (res_in) {
-        for (int i = threadIdx.x * 4; i < vol; i += MID_THREADS * 4) {
-            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(ys + i) = *reinterpret_cast<const f32x4 *>(res_in + blk + i);
-            else for (int e = i; e < vol; ++e) ys[e] = res_in[blk + e];
-        }
-        __syncthreads();
-    }
-    // ---- phase 1: M -> y (A^T along W, H per depth plane of M; D as an accumulation) ----
-#ifndef MID_NO_P1
+    const int items = nts * 4;
     for (int it = threadIdx.x; it < items; it += MID_THREADS) {
         const int ch = it & 3, tl = it >> 2;
         const int co = cq * 4 + ch;
@@ -648,6 +633,32 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
                 }
             }
     }
+}
+
+__global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
+    const float *__restrict__ M, float *__restrict__ V, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ res_in, float *__restrict__ res_out, Tiling g,
+    int C, int nt, int relu) {
+    extern __shared__ float ys[];                       // [D][H][4][Wp]
+    constexpr int T = 6, O = 4;
+    const int Wp = g.W | 1, vol = g.D * g.H * 4 * Wp;
+    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;     // quads with data, quads per transform point
+    const int b = blockIdx.x / nq, cq = blockIdx.x - b * nq;
+    const int nts = g.Td * g.Th * g.Tw, items = nts * 4;
+    const int xs = Q * nt * 16;                         // bytes between transform points
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, 216 * xs, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, 216 * xs, 0x00020000);
+    const size_t blk = ((size_t)b * nq + cq) * vol;     // this workgroup's block of R
+    if (res_in) {
+        for (int i = threadIdx.x * 4; i < vol; i += MID_THREADS * 4) {
+            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(ys + i) = *reinterpret_cast<const f32x4 *>(res_in + blk + i);
+            else for (int e = i; e < vol; ++e) ys[e] = res_in[blk + e];
+        }
+        __syncthreads();
+    }
+    // ---- phase 1: M -> y ----
+#ifndef MID_NO_P1
+    wino_output_phase(mr, ys, g, Wp, cq, b, nts, nt, xs, scale, shift, C, relu, res_in != nullptr);
 #endif
     __syncthreads();
     if (res_out) {
@@ -671,6 +682,122 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
         else mid_input_half<1>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
     }
 #endif
+}
+
+// ---- output transform of the LAST C -> C layer + the 216 -> 1 convolution (submodule.py:648, 661) ----
+// The last unit (Conv3d(C, 1, 3) + BN) needs every channel of y at 27 taps; a workgroup here holds FOUR channels of a
+// sample (phase 1 above), so it forms ITS share of the 27-tap sum for every voxel out of LDS,
+//     part[b][quad][d][y][x] = sum_{c in quad} sum_tap w[c][tap] * y[c][d + dz][y + dy][x + dx],
+// and cout1_reduce_softargmax adds the C / 4 shares in a fixed order, applies the folded BN and the soft-argmax
+// (disparity_regression, submodule.py:766-777).  y of the last 216-channel layer is never written: 134 MB of M in,
+// 10 MB of partial sums out, instead of y out (40 MB), y in, tap products out and in.  MEASURED SLOWER than the three
+// kernels it replaces (72 + 6 us against 42 + 14 + 11 us at config 2: the tap loops are 108 dependent LDS / scalar-load
+// steps per output group on two waves per SIMD; with the weights in registers the kernel spills: 95 us), so
+// decnet_stage0_forward uses it only with DECNET_WINO_TAIL=1; the entry and its parity test stay.
+__global__ __launch_bounds__(MID_THREADS) void wino_tail_transform(
+    const float *__restrict__ M, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ w_last, float *__restrict__ part, Tiling g, int C, int nt, int relu) {
+    extern __shared__ float ys[];                       // [D][H][4][Wp]
+    const int D = g.D, H = g.H, W = g.W, Wp = W | 1, vol = D * H * 4 * Wp;
+    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;
+    const int b = blockIdx.x / nq, cq = blockIdx.x - b * nq;
+    const int nts = g.Td * g.Th * g.Tw;
+    const int xs = Q * nt * 16;
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, 216 * xs, 0x00020000);
+    // W even: the pad column x = W of every row (Wp = W + 1) is zeroed, so that x0 - 1 = -1 (the previous row's pad column;
+    // below the allocation for the very first row: LDS reads there return zero) and x0 + 4 = W read zeros without a test
+    const bool padded = (W & 1) == 0;
+    if (padded)
+        for (int r = threadIdx.x; r < D * H * 4; r += MID_THREADS) ys[r * Wp + W] = 0.f;
+    wino_output_phase(mr, ys, g, Wp, cq, b, nts, nt, xs, scale, shift, C, relu, false);
+    __syncthreads();
+    // a thread per four consecutive x of one (d, y): six values of every (tap row, channel) feed four outputs; the
+    // weights are uniform over the workgroup: scalar loads straight from w_last
+    const int gx = (W + 3) >> 2, ngr = D * H * gx;
+    float *out = part + ((size_t)b * nq + cq) * D * H * W;
+    const float *wq = w_last + (size_t)cq * 4 * 27;
+    const int nch = C - cq * 4 < 4 ? C - cq * 4 : 4;
+    for (int gi = threadIdx.x; gi < ngr; gi += MID_THREADS) {
+        const int x4 = gi % gx, zy = gi / gx, y = zy % H, z = zy / H, x0 = 4 * x4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int zz = z + dz - 1;
+            if ((unsigned)zz >= (unsigned)D) continue;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= nch) break;
+                    const float *row = ys + ((zz * H + yy) * 4 + c) * Wp + x0 - 1;
+                    float v[6];
+                    if (padded) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) v[k] = row[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int xx = x0 - 1 + k;
+                            const float t = row[(unsigned)xx < (unsigned)W ? k : 1];
+                            v[k] = (unsigned)xx < (unsigned)W ? t : 0.f;
+                        }
+                    }
+                    const float *wr = wq + c * 27 + (dz * 3 + dy) * 3;
+                    const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(v[i + 2], w2, fmaf(v[i + 1], w1, fmaf(v[i], w0, acc[i])));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x0 + i < W) out[(size_t)zy * W + x0 + i] = acc[i];
+    }
+}
+
+// cost[b][d][y][x] = (sum over the quads' shares, in quad order) * scale + shift -> reg (optional) and the soft-argmax over d
+__global__ __launch_bounds__(256) void cout1_reduce_softargmax(const float *__restrict__ part, float scale, float shift,
+                                                               float *__restrict__ reg, float *__restrict__ pred,
+                                                               int B, int D, int H, int W, int nq, int PB) {
+    extern __shared__ float costs[];                   // [PB][D]
+    const int npix = B * H * W, plane = H * W;
+    const int d = threadIdx.x / PB, pl = threadIdx.x - d * PB;     // lanes along the pixels: coalesced shares
+    const int pix = blockIdx.x * PB + pl;
+    if (d < D && pix < npix) {
+        const int b = pix / plane, yx = pix - b * plane;
+        const float *p0 = part + ((size_t)b * nq * D + d) * plane + yx;
+        // six independent chains (q mod 6), combined in a fixed order: the loads of a chain step are in flight together
+        float a6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const size_t qs = (size_t)D * plane;
+        int q = 0;
+        for (; q + 6 <= nq; q += 6) {
+            float t[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) t[e] = p0[(size_t)(q + e) * qs];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) a6[e] += t[e];
+        }
+        for (int e = 0; q < nq; ++q, ++e) a6[e] += p0[(size_t)q * qs];
+        const float acc = ((a6[0] + a6[1]) + (a6[2] + a6[3])) + (a6[4] + a6[5]);
+        const float cost = fmaf(acc, scale, shift);
+        costs[pl * D + d] = cost;
+        if (reg) reg[((size_t)b * D + d) * plane + yx] = cost;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < PB && (int)(blockIdx.x * PB + threadIdx.x) < npix) {
+        float m = -INFINITY, S = 0.f, Tt = 0.f;
+        for (int dd = 0; dd < D; ++dd) {
+            const float cost = costs[threadIdx.x * D + dd];
+            const float mn = fmaxf(m, cost);
+            const float r = expf(m - mn), e = expf(cost - mn);       // m = -inf -> r = 0
+            S = fmaf(S, r, e);
+            Tt = fmaf(Tt, r, e * (float)dd);
+            m = mn;
+        }
+        pred[blockIdx.x * PB + threadIdx.x] = Tt / S;
+    }
 }
 
 // ---- cost volume + input transform of the first layer (the cost volume never reaches HBM) ----
@@ -1436,10 +1563,16 @@ size_t head_lds_bytes(int D, int H, int W) {
 
 // x != nullptr: the stack's input is a channels-last volume; x == nullptr: it is the cost volume of (left, right),
 // formed on chip by wino_head_transform
+struct StackTail {                                      // the 216 -> 1 unit + soft-argmax behind the stack (w == nullptr: none)
+    const float *w;
+    float scale, shift;
+    float *reg, *pred;
+};
+
 int conv_stack(const float *x, const float *left, const float *right, const float *const *u,
                const float *const *scale, const float *const *shift,
                int n_layers, int res_src, int res_dst, float *y, float *workspace, float *R, int B, int D, int H,
-               int W, int C, hipStream_t s) {
+               int W, int C, hipStream_t s, StackTail tail = StackTail{nullptr, 0.f, 0.f, nullptr, nullptr}) {
     constexpr int NP = 216;
     Tiling g{D, H, W, ceil_div(D, 4), ceil_div(H, 4), ceil_div(W, 4)};
     const int nt = B * g.Td * g.Th * g.Tw;
@@ -1475,10 +1608,27 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
     if (rc) return rc;
     for (int i = 0; i < n_layers; ++i) {
         const bool last = i == n_layers - 1;
-        // V of layer 0 comes from wino_input_transform (chunk major), M of the last layer goes to
-        // wino_output_transform (chunk major); everything between is quad major
-        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0 || !x, !last))) return rc;
-        if (last) {
+        // V of layer 0 comes from wino_input_transform (chunk major) unless the head kernel forms it, M of the last layer
+        // goes to wino_output_transform (chunk major) unless the tail kernel takes it; everything between is quad major
+        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0 || !x, !last || tail.w))) return rc;
+        if (last && tail.w) {
+            // (R is free again: res_dst < n_layers - 1)
+            const size_t tl = lds;
+            static size_t tl_set = 0;
+            if (tl > tl_set) {
+                if (hipFuncSetAttribute((const void *)wino_tail_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return DECNET_ERR_UNSUPPORTED;
+                }
+                tl_set = tl;
+            }
+            hipLaunchKernelGGL(wino_tail_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), tl, s, M,
+                               scale[i], shift[i], tail.w, R, g, C, nt, 1);
+            if ((rc = decnet_launch_status())) return rc;
+            const int PB = 256 / D, npix = B * H * W;
+            hipLaunchKernelGGL(cout1_reduce_softargmax, dim3((unsigned)ceil_div(npix, PB)), dim3(256), (size_t)PB * D * 4, s,
+                               R, tail.scale, tail.shift, tail.reg, tail.pred, B, D, H, W, (C + 3) / 4, PB);
+        } else if (last) {
             const size_t n = (size_t)nt * pad16(C);
             hipLaunchKernelGGL((wino_output_transform<6, 6, 6, 1>), dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, s,
                                M, scale[i], shift[i], (const float *)nullptr, y, g, C, 1, 0, nt, bytes);
@@ -1615,6 +1765,28 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
     const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
     return conv_stack(nullptr, left, right, u, scale, shift, n_layers, res_src, res_dst, y, workspace, workspace + w, B, D, H,
                       W, C, (hipStream_t)stream);
+}
+
+/* decnet_costvol_wino_stack_bn_act + the last unit of CostRegNetNoDown (Conv3d(C, 1, 3) + BN, submodule.py:648, 661;
+ * w_last = its torch weight [1][C][3][3][3], BN folded to scale_last / shift_last) + disparity_regression
+ * (submodule.py:766-777, samples 0 .. D-1): reg [B,D,H,W] (may be NULL) and pred [B,H,W].  The output of the last
+ * C -> C layer is never written: its output transform forms the 27-tap sums of four channels at a time out of LDS. */
+int decnet_costvol_wino_stack_softargmax(const float *left, const float *right, const float *const *u,
+                                         const float *const *scale, const float *const *shift, int n_layers, int res_src,
+                                         int res_dst, const float *w_last, float scale_last, float shift_last, float *reg,
+                                         float *pred, float *workspace, int B, int C, int H, int W, int D, int variant,
+                                         void *stream) {
+    if (!left || !right || !u || !scale || !shift || !w_last || !pred || !workspace) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || D < 1 || H < 2 || W < 2 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    for (int i = 0; i < n_layers; ++i)
+        if (!u[i] || !scale[i] || !shift[i]) return DECNET_ERR_NULL_POINTER;
+    if ((res_src < 0) != (res_dst < 0)) return DECNET_ERR_BAD_SHAPE;
+    if (res_src >= 0 && !(res_src < res_dst && res_dst < n_layers - 1)) return DECNET_ERR_UNSUPPORTED;
+    if (D > 256 || n_layers < 2 || !stack_ok(B, D, H, W, C, variant) || head_lds_bytes(D, H, W) > 160 * 1024)
+        return DECNET_ERR_UNSUPPORTED;
+    const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
+    return conv_stack(nullptr, left, right, u, scale, shift, n_layers, res_src, res_dst, nullptr, workspace, workspace + w, B,
+                      D, H, W, C, (hipStream_t)stream, StackTail{w_last, scale_last, shift_last, reg, pred});
 }
 
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale, const float *shift,

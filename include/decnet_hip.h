@@ -174,6 +174,14 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
                                      const float *const *scale, const float *const *shift, int n_layers, int res_src,
                                      int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
                                      int variant, void *stream);
+/* ... and with the last unit of CostRegNetNoDown (Conv3d(C, 1, 3) + BN, submodule.py:648, 661: w_last = its torch weight
+ * [1][C][3][3][3], BN folded to scale_last / shift_last) and disparity_regression (submodule.py:766-777, samples 0..D-1)
+ * behind it: reg [B,D,H,W] (may be NULL), pred [B,H,W].  The last C -> C layer's output is never written either. */
+int decnet_costvol_wino_stack_softargmax(const float *left, const float *right, const float *const *u,
+                                         const float *const *scale, const float *const *shift, int n_layers, int res_src,
+                                         int res_dst, const float *w_last, float scale_last, float shift_last, float *reg,
+                                         float *pred, float *workspace, int B, int C, int H, int W, int D, int variant,
+                                         void *stream);
 
 /* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
  * over disp_samples = arange(D) (submodule.py:766-777):
