@@ -526,6 +526,33 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const unsigned long long *tbits = reinterpret_cast<const unsigned long long *>(tmask) + (size_t)row * ((W + 63) >> 6);
     const unsigned long long *lbits = reinterpret_cast<const unsigned long long *>(rmask) + (size_t)row * ((W + 63) >> 6);
 
+    // fp32 layouts (stages 1, 2): the first pass of the R staging and the left operand of this wave's first tile are
+    // requested BEFORE the mask phase -- neither depends on it -- so that a dense row pays one memory round trip where it
+    // paid three (masks, then R, then, behind the barrier, the left operand)
+    const bool al_r = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+    const int st_nq = nRw >> 2;                      // 16-byte groups per channel row of the staged window (<= THREADS)
+    const int st_rpp = THREADS / st_nq;              // channel rows per pass
+    const int st_r0 = tid / st_nq, st_jq = tid - st_r0 * st_nq;
+    float4 st_v[D16 ? 1 : 8];
+    float bfirst[(!D16 && KQ > 0) ? KQ : 1];
+    if constexpr (!D16) {
+        if (st_r0 < st_rpp) {
+            const int x = xs - HALO + 4 * st_jq;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = st_r0 + u * st_rpp;
+                st_v[u] = c < C ? load4(rrow + (size_t)c * plane, x, W, al_r) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if constexpr (KQ > 0) {
+            const int jl = lane & 15, ql = lane >> 4;
+            const int x = xs + wave * 16 + jl;
+            const bool ok = wave < XT && x < W;
+#pragma unroll
+            for (int s = 0; s < KQ; ++s) bfirst[s] = (ok && 4 * s + ql < C) ? lrow[(size_t)(4 * s + ql) * plane + x] : 0.f;
+        }
+    }
+
     // ---------------- phase 1: masks -> LDS, flags kept in registers, block-wide counts ----------
     const int p4 = tid * 4;                          // this thread's 4 positions (RP, SW <= 2048)
     int fr = 0, fl = 0;                              // 4 right / left activity bits
@@ -595,18 +622,22 @@ __device__ __forceinline__ void spamat_fwd_segment(
     // every thread has up to 8 loads in flight before its stores (stage 1, C = 72 over 144 positions:
     // 6 loads per thread instead of 72 serial ones on 36 threads).
     {
-        const bool al = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
-        const int nq = nRw >> 2;                             // 16-byte groups per channel row (<= THREADS)
-        const int rpp = THREADS / nq;                        // channel rows per pass
-        const int r0 = tid / nq, jq = tid - r0 * nq;
+        const bool al = al_r;
+        const int rpp = st_rpp;
+        const int r0 = st_r0, jq = st_jq;
         if (r0 < rpp) {
             const int jj = 4 * jq, x = xs - HALO + jj;
             for (int c0 = r0; c0 < lo.Cq; c0 += 8 * rpp) {
                 float4 v[8];
+                if (!D16 && c0 == r0) {                 // the first pass was requested at the top
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + u * rpp;
-                    v[u] = c < C ? load4(rrow + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < 8; ++u) v[u] = st_v[D16 ? 0 : u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + u * rpp;
+                        v[u] = c < C ? load4(rrow + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -649,7 +680,12 @@ __device__ __forceinline__ void spamat_fwd_segment(
         };
         constexpr bool PREF = KQ <= 6;                  // next tile's left operand in flight (C = 72: no room, and
                                                         // stage 1 has one tile per wave anyway)
-        if constexpr (PREF) fetch_left(wave, bv);
+        if constexpr (PREF && KQ > 0) {
+#pragma unroll
+            for (int s = 0; s < KB; ++s) bv[s] = bfirst[s];      // this wave's first tile: requested at the top
+        } else if constexpr (PREF) {
+            fetch_left(wave, bv);
+        }
         for (int xt = wave; xt < XT; xt += NWAVE) {
             const int x0 = xs + xt * 16;
             if (x0 >= W) break;
@@ -661,6 +697,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
 #pragma unroll
                 for (int s = 0; s < KB; ++s) bcur[s] = bv[s];
                 fetch_left(xt + NWAVE, bv);             // prefetch the next tile's left operand
+            } else if (KQ > 0 && xt == wave) {
+#pragma unroll
+                for (int s = 0; s < KB; ++s) bcur[s] = bfirst[KQ > 0 ? s : 0];
             } else {
                 fetch_left(xt, bcur);
             }
