@@ -338,13 +338,31 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
 // ~5 % of the softmax work instead of ~20 %.  LDS: 48 bytes per staged position and channel group for each
 // side, so a 972-pixel row of stage 3 is two segments (63 KB each, two workgroups per CU).
 // BX (right-mask bias) and LM (left mask) are filled by the caller's phase 1.
-template <int NT, int MODE, int CGT>
+// the loads of staging item `it` of dense16_body(xs, SW, HALO, nRw): 8 channels x 4 positions of one view
+__device__ __forceinline__ void dense16_item_loads(float4 (&v)[8], int it, const float *__restrict__ lrow,
+                                                   const float *__restrict__ rrow, size_t plane, int C, int W, int xs,
+                                                   int SW, int HALO, int nRw) {
+    const bool al = ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+    const int cg_n = (C + 7) >> 3, nqR = nRw >> 2, nqL = SW >> 2;
+    const int nR_items = cg_n * nqR;
+    const bool isL = it >= nR_items;
+    const int k = isL ? it - nR_items : it, nq = isL ? nqL : nqR;
+    const int g = k / nq, jq = k - g * nq;
+    const float *src = isL ? lrow : rrow;
+    const int x = isL ? xs + 4 * jq : xs - HALO + 4 * jq;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        v[c] = 8 * g + c < C ? load4(src + (size_t)(8 * g + c) * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// pre: the loads of this thread's first staging item (it = tid), requested by the caller before the mask phase (PRE)
+template <int NT, int MODE, int CGT, bool PRE = false>
 __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const float *LM, const float *smem,
                                              const float *__restrict__ lrow, const float *__restrict__ rrow,
                                              const float *__restrict__ disparity, float *__restrict__ out,
                                              float *__restrict__ var_out, float *__restrict__ sum_sim,
                                              float *__restrict__ max_cost, size_t plane, size_t rowpix, int C, int W,
-                                             int D, int xs, int XT, int SW, int HALO, int nRw) {
+                                             int D, int xs, int XT, int SW, int HALO, int nRw, const float4 *pre = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     struct { int CG; } lo = {(C + 7) >> 3};
     int *LT = RT + 3 * lo.CG * nRw * 4;
@@ -361,9 +379,14 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
             const float *src = isL ? lrow : rrow;
             const int x = isL ? xs + 4 * jq : xs - HALO + 4 * jq;
             float4 v[8];
+            if (PRE && it == tid) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                v[c] = 8 * g + c < C ? load4(src + (size_t)(8 * g + c) * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = 0; c < 8; ++c) v[c] = pre[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    v[c] = 8 * g + c < C ? load4(src + (size_t)(8 * g + c) * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             int *dst = (isL ? LT : RT) + (g * (isL ? SW : nRw) + 4 * jq) * 4;
             const int tstride = cg_n * (isL ? SW : nRw) * 4;              // words between terms
 #pragma unroll
@@ -526,6 +549,14 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const unsigned long long *tbits = reinterpret_cast<const unsigned long long *>(tmask) + (size_t)row * ((W + 63) >> 6);
     const unsigned long long *lbits = reinterpret_cast<const unsigned long long *>(rmask) + (size_t)row * ((W + 63) >> 6);
 
+    // bf16 layout (stage 3 dense rows): the loads of this thread's first staging item of the first half pass, requested
+    // before the mask phase too (a compact row wastes them)
+    float4 d16_pre[D16 ? 8 : 1];
+    if constexpr (D16) {
+        const int xta = (XT + 1) / 2;
+        const int n_items = ((C + 7) >> 3) * (((HALO + xta * 16) >> 2) + ((xta * 16) >> 2));
+        if (tid < n_items) dense16_item_loads(d16_pre, tid, lrow, rrow, plane, C, W, xs, xta * 16, HALO, HALO + xta * 16);
+    }
     // fp32 layouts (stages 1, 2): the first pass of the R staging and the left operand of this wave's first tile are
     // requested BEFORE the mask phase -- neither depends on it -- so that a dense row pays one memory round trip where it
     // paid three (masks, then R, then, behind the barrier, the left operand)
@@ -605,9 +636,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
             // channel group, and the segment partition (= the number of workgroups of a marker launch, the
             // compact path's halos) stays the fp32 layout's
             const int xta = (XT + 1) / 2, xtb = XT - xta;
-            dense16_body<NT, MODE, (KQ + 1) / 2>(reinterpret_cast<int *>(Rs), BX, LM, smem, lrow, rrow, disparity, out,
-                                                 var_out, sum_sim, max_cost, plane, rowpix, C, W, D, xs, xta, xta * 16,
-                                                 HALO, HALO + xta * 16);
+            dense16_body<NT, MODE, (KQ + 1) / 2, true>(reinterpret_cast<int *>(Rs), BX, LM, smem, lrow, rrow, disparity, out,
+                                                       var_out, sum_sim, max_cost, plane, rowpix, C, W, D, xs, xta, xta * 16,
+                                                       HALO, HALO + xta * 16, d16_pre);
             if (xtb > 0 && xs + xta * 16 < W) {
                 __syncthreads();
                 dense16_body<NT, MODE, (KQ + 1) / 2>(reinterpret_cast<int *>(Rs), BX + xta * 16, LM + xta * 16, smem, lrow,
