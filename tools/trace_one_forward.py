@@ -1,5 +1,5 @@
 """Per-kernel time of ONE steady-state forward out of a rocprofv3 kernel trace of tools/e2e_profile.py
-(the span between the last two launches of costvol_cor_ndhwc).  python tools/trace_one_forward.py <dir>"""
+(the span between the last two launches of the stage-0 head kernel).  python tools/trace_one_forward.py <dir>"""
 import collections
 import csv
 import glob
@@ -7,7 +7,9 @@ import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "costvol_cor_ndhwc" in r["Kernel_Name"]]
+# one launch per forward: the stage-0 head (cost volume formed on chip) or, on the unfused path, the cost-volume kernel
+idx = [i for i, r in enumerate(rows) if "wino_head_transform" in r["Kernel_Name"]] or \
+      [i for i, r in enumerate(rows) if "costvol_cor_ndhwc" in r["Kernel_Name"]]
 seg = rows[idx[-2]:idx[-1]]
 span = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
 agg = collections.defaultdict(lambda: [0, 0.0])
