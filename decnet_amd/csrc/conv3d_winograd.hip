@@ -1461,13 +1461,10 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
         static const int use_lds = [] { const char *e = getenv("DECNET_WINO_GEMM_LDS"); return e ? atoi(e) : 0; }();
         if (use_lds && tm == 3) {
             constexpr int lds = 2 * 3 * 14 * 1024;
-            static int lds_set = 0;
-            if (!lds_set) {
-                if (hipFuncSetAttribute((const void *)wino_gemm_bf16x3_lds<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return DECNET_ERR_UNSUPPORTED;
-                }
-                lds_set = 1;
+            // (the attribute is per device: set per launch, it is cheap)
+            if (hipFuncSetAttribute((const void *)wino_gemm_bf16x3_lds<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                (void)hipGetLastError();
+                return DECNET_ERR_UNSUPPORTED;
             }
             hipLaunchKernelGGL((wino_gemm_bf16x3_lds<7>), dim3(ceil_div(nt, 192), np), dim3(512), lds, s, V, Ub, M, nt, Ci,
                                Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
@@ -1579,13 +1576,10 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
     float *V = workspace, *M = workspace + (size_t)NP * nt * pad16(C);
     const int bytes = (int)((size_t)B * D * H * W * C * 4);
     const size_t lds = stack_lds_bytes(D, H, W);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void *)wino_mid_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return DECNET_ERR_UNSUPPORTED;
-        }
-        lds_set = lds;
+    // more than 64 KiB of dynamic LDS needs the attribute; it is per device, so it is set per call (cheap) rather than cached
+    if (hipFuncSetAttribute((const void *)wino_mid_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return DECNET_ERR_UNSUPPORTED;
     }
     if (x) {
         const int ith = C >= 256 ? 256 : (C + 63) / 64 * 64;
@@ -1593,13 +1587,9 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
                            dim3(ith), 0, s, x, V, g, C, 0, nt, bytes);
     } else {
         const size_t hl = head_lds_bytes(D, H, W);
-        static size_t hl_set = 0;
-        if (hl > hl_set) {
-            if (hipFuncSetAttribute((const void *)wino_head_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl) != hipSuccess) {
-                (void)hipGetLastError();
-                return DECNET_ERR_UNSUPPORTED;
-            }
-            hl_set = hl;
+        if (hipFuncSetAttribute((const void *)wino_head_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl) != hipSuccess) {
+            (void)hipGetLastError();
+            return DECNET_ERR_UNSUPPORTED;
         }
         hipLaunchKernelGGL(wino_head_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), hl, s, left, right, V,
                            g, C, nt);
@@ -1614,13 +1604,9 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
         if (last && tail.w) {
             // (R is free again: res_dst < n_layers - 1)
             const size_t tl = lds;
-            static size_t tl_set = 0;
-            if (tl > tl_set) {
-                if (hipFuncSetAttribute((const void *)wino_tail_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return DECNET_ERR_UNSUPPORTED;
-                }
-                tl_set = tl;
+            if (hipFuncSetAttribute((const void *)wino_tail_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl) != hipSuccess) {
+                (void)hipGetLastError();
+                return DECNET_ERR_UNSUPPORTED;
             }
             hipLaunchKernelGGL(wino_tail_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), tl, s, M,
                                scale[i], shift[i], tail.w, R, g, C, nt, 1);

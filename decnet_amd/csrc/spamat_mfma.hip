@@ -1301,12 +1301,10 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
             const size_t mlds = 4 * sparse_row_words(2, 4, SP_THREADS, MID_CAP);
 #define LAUNCHM(M)                                                                                 \
     do {                                                                                           \
-        static bool set_##M = false;                                                               \
-        if (!set_##M) {                                                                            \
+        if (mlds > 64 * 1024) {                                                                    \
             hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_sparse_mid<NT, M, 2, 4>,   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); \
             if (e != hipSuccess) return (int)e;                                                    \
-            set_##M = true;                                                                        \
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_sparse_mid<NT, M, 2, 4>), dim3((unsigned)(B * H)), dim3(SP_THREADS), mlds, stream, \
                            ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, XT * 16, \
