@@ -301,6 +301,53 @@ def pack_mask_bits(mask):
     return (z.view(B, H, wpr, 64) << sh).sum(-1).contiguous()
 
 
+def live_traffic(config):
+    """HBM-side bytes per launch of the dominant kernel, counted in THIS run: two child processes under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (counters need the profiler around the process; separate passes,
+    no trace domains -- MI355X_MICROARCH.md) run three steps of this same script with every other leg switched off, and
+    the per-launch means of the GEMM kernel are read back (tools/pmc_summary.py: FETCH_SIZE doubled on gfx950).  Returns
+    (bytes, note) or (None, reason): any failure -- no rocprofv3, no counter access, a time-out -- leaves the committed
+    profiles/traffic.json figure in place."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import means
+    except ImportError as e:
+        return None, "tools/pmc_summary.py: %s" % e
+    tmp = tempfile.mkdtemp(prefix="decnet_pmc_", dir="/tmp")
+    res = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--config", str(config), "--steps", "3", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-e2e", "--no-train", "--no-density-sweep", "--no-alt", "--no-valu-floor",
+                   "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d" % (counter, r.returncode)
+            m = {k: v for k, v in means(d, counter).items() if "wino_gemm_bf16x3" in k or "wino_gemm_persist<" in k or
+                 "wino_gemm<" in k or "conv3d_k3_igemm" in k}
+            if not m:
+                return None, "no dominant-kernel rows in the %s pass" % counter
+            tot = sum(n for _, n in m.values())
+            res[counter] = sum(a * n for a, n in m.values()) / tot
+        return 2.0 * 1024.0 * res["FETCH_SIZE"] + 1024.0 * res["WRITE_SIZE"], \
+            "counted in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of 3 steps (FETCH_SIZE x 2 x 1024 + " \
+            "WRITE_SIZE x 1024 bytes per launch, tools/pmc_summary.py)"
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError, IndexError) as e:
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def alt_gemm_leg():
     """The hot-path step once more in a child process with the fp32 MFMA Winograd GEMM (DECNET_WINO_GEMM=fp32; the
     switch is read once per process and changes the packed weights): value / ms_per_step / GEMM ms of round 2's
@@ -308,7 +355,7 @@ def alt_gemm_leg():
     import subprocess
     env = dict(os.environ, DECNET_WINO_GEMM="fp32")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "50", "--warmup", "8", "--no-cpu-baseline", "--no-train",
-           "--no-density-sweep", "--no-e2e", "--no-alt"]
+           "--no-density-sweep", "--no-e2e", "--no-alt", "--no-live-traffic", "--no-valu-floor"]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -606,6 +653,9 @@ def main():
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the 'alt_wino_gemm_fp32' object: the same hot-path step in a child process with "
                          "DECNET_WINO_GEMM=fp32 (the Winograd GEMMs on fp32 MFMA, round 2's default)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from profiles/traffic.json instead of counting it in two rocprofv3 --pmc "
+                         "child passes of this run (profiling runs; the child passes themselves)")
     ap.add_argument("--no-valu-floor", action="store_true",
                     help="skip the live VALU-floor microbenchmark (a child process; profiling runs)")
     ap.add_argument("--force-collective", action="store_true",
@@ -820,7 +870,8 @@ def main():
             # against the dense bf16 peak; fp32_equivalent_tflops = algorithmic flops / time (157.3 would be the fp32 peak)
             "roofline": {"bound": "mfma", "achieved": gemm_mult * kern_flop / conv_ms / 1e9, "peak": gemm_peak,
                          "unit": "TFLOP/s", "frac": gemm_mult * kern_flop / conv_ms / 1e9 / gemm_peak,
-                         "traffic": traffic.get(tkey, {}).get("total_bytes"), "kernel": kern_name,
+                         "traffic": traffic.get(tkey, {}).get("total_bytes"),
+                         "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes)", "kernel": kern_name,
                          "ms": conv_ms, "flop_per_launch": gemm_mult * kern_flop, "algorithmic_flop_per_launch": kern_flop,
                          "fp32_equivalent_tflops": kern_flop / conv_ms / 1e9,
                          "fp32_equivalent_frac_of_fp32_mfma_peak": kern_flop / conv_ms / 1e9 / MFMA_F32_PEAK_TF,
@@ -871,6 +922,15 @@ def main():
                 out["value_end_to_end"] = max(out["e2e"]["value"], hg.get("value", 0.0))
             except Exception as e:                      # never lose the bench line to the extra leg
                 out["e2e"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if world == 1 and not args.no_live_traffic:
+            # roofline.traffic counted in this run (two rocprofv3 --pmc child passes); the committed figure stays on failure
+            tb, note = live_traffic(args.config)
+            if tb is not None:
+                out["roofline"]["traffic_committed"] = out["roofline"]["traffic"]
+                out["roofline"]["traffic"] = tb
+                out["roofline"]["traffic_source"] = note
+            else:
+                out["roofline"]["traffic_source"] += "; live count not available (%s)" % note
         if (world == 1 and not args.no_alt and args.config == 2 and args.mask_density >= 1.0 and
                 os.environ.get("DECNET_WINO_GEMM", "") == ""):
             out["alt_wino_gemm_fp32"] = alt_gemm_leg()

@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
+def _run(*flags, live_traffic=False):
+    # (the live PMC count of roofline.traffic is two more child processes under rocprofv3: its own test below)
+    if not live_traffic:
+        flags = flags + ("--no-live-traffic",)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", *flags],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -144,3 +147,20 @@ def test_bench_collectives_run_through_rccl_in_a_world_of_one():
     # plain `python bench.py --force-collective` (no launcher): a world of one by itself
     d = _run("--force-collective", "--no-e2e", "--no-train", "--no-density-sweep", "--no-cpu-baseline", "--no-alt")
     assert d["collective"]["backend"] == "nccl" and d["collective"]["own_shard_equals_sent"] is True
+
+
+def test_roofline_traffic_is_counted_in_the_run():
+    """Without --no-live-traffic bench.py counts the dominant kernel's HBM-side bytes itself (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE child passes) instead of quoting profiles/traffic.json; the two must agree (the committed figure is the
+    same measurement from tools/profile_round.sh)."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    d = _run("--no-e2e", "--no-train", "--no-density-sweep", "--no-cpu-baseline", "--no-alt", "--no-valu-floor",
+             live_traffic=True)
+    r = d["roofline"]
+    assert r["traffic_source"].startswith("counted in this run"), r["traffic_source"]
+    # V in + split U^T in + M out of the GEMM: 139 + 62 + 139 MB algorithmic
+    assert 0.8 * 340e6 < r["traffic"] < 1.3 * 340e6, r["traffic"]
+    if r.get("traffic_committed"):
+        assert abs(r["traffic"] - r["traffic_committed"]) < 0.15 * r["traffic_committed"]
