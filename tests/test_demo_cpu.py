@@ -90,3 +90,26 @@ def test_checkpoint_loader_is_strict():
     with pytest.raises(RuntimeError, match="cost_regularizer.conv0.0.conv.weight"):
         load_reference_checkpoint(b, part)
     load_reference_checkpoint(b, part, strict=False)                                # the reference's behaviour
+
+
+def test_host_detail_mask_primitives_against_scipy_and_torch():
+    """cv2 is absent here, so decnet_amd.masks cannot be pinned against the library the reference calls
+    (utils/utils.py:447-534).  The two primitives are pinned against two OTHER independent implementations of the same
+    published semantics instead: cv2.GaussianBlur(k, sigma=1, BORDER_REFLECT_101) == a separable correlation with
+    exp(-x^2/2)/sum and scipy's 'mirror' boundary; cv2.resize(..., INTER_LINEAR) == half-pixel-centre bilinear without
+    antialiasing, clamped at the border == torch's bilinear interpolate with align_corners=False."""
+    import numpy as np
+    import scipy.ndimage as nd
+    from decnet_amd.masks import gaussian_blur, resize_linear
+    rng = np.random.default_rng(5)
+    img = rng.random((31, 44, 3)).astype(np.float32)
+    for k in (3, 5, 7):
+        x = np.arange(k, dtype=np.float64) - (k - 1) / 2
+        g = np.exp(-x * x / 2.0)
+        g /= g.sum()
+        ref = nd.correlate1d(nd.correlate1d(img.astype(np.float64), g, axis=1, mode="mirror"), g, axis=0, mode="mirror")
+        np.testing.assert_allclose(gaussian_blur(img, k), ref, rtol=0, atol=2e-6)
+    t = torch.from_numpy(img).permute(2, 0, 1)[None]
+    for (ho, wo) in ((10, 14), (93, 132), (31, 44), (17, 50)):
+        ref = torch.nn.functional.interpolate(t, size=(ho, wo), mode="bilinear", align_corners=False, antialias=False)
+        np.testing.assert_allclose(resize_linear(img, ho, wo), ref[0].permute(1, 2, 0).numpy(), rtol=0, atol=5e-6)
