@@ -4,7 +4,9 @@ channels, min-max normalised and thresholded.  Not on the GPU hot path (the ship
 --use_detail=1 and never call it); numpy only, no cv2.
 
 The reference's arithmetic lives in OpenCV, which is absent here, so this restatement follows the
-published semantics of the three calls it makes and is *parity unpinned* against cv2 itself:
+published semantics of the three calls it makes and is *parity unpinned* against cv2 itself (the two primitives are
+pinned against scipy.ndimage and torch's bilinear interpolate, two independent implementations of those semantics:
+tests/test_demo_cpu.py):
   * cv2.GaussianBlur(img, (k,k), 1): separable kernel exp(-x^2/2)/sum, BORDER_REFLECT_101;
   * cv2.resize(img, dsize, cv2.INTER_AREA): the third positional argument of cv2.resize is `dst`, not
     the interpolation flag, so the reference actually resizes with the default INTER_LINEAR --
