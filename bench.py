@@ -330,7 +330,7 @@ def live_traffic(config):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s exited with %d" % (counter, r.returncode)
             m = {k: v for k, v in means(d, counter).items() if "wino_gemm_bf16x3" in k or "wino_gemm_persist<" in k or
