@@ -1306,7 +1306,9 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3
 // double buffered, one barrier per k pair; V stays register-direct.  Requests per 32 k and workgroup: 42 + 48 instead
 // of 2 x (84 + 24) for the same rows.
 #define LDS_PTR3(p) ((__attribute__((address_space(3))) void *)(p))
-template <int NPAIR>
+// DMA = false: the workgroup's share of the U^T terms goes global -> registers (buffer_load_b128, 5 - 6 per wave) ->
+// ds_write_b128 instead of LDS-DMA (whose 16-byte form may cost the texture path as much as four dword loads).
+template <int NPAIR, bool DMA = true>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_bf16x3_lds(
     const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
     int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs) {
@@ -1337,14 +1339,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // copy q of a k pair = (term q / 14, 16-co tile q % 14): the lane's source is where it would load the operand from
     const int u_src = i16 * 64 + kq * 16 + pt * u_point;
+    i32x4 ust[DMA ? 1 : 6];                            // DMA = false: this wave's copies in flight
     auto dma = [&](int p, int buf) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int q = wave + 8 * k;
             if (q < 42) {
                 const int term = q / 14, jt = q - term * 14;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, LDS_PTR3(ulds + buf * UBUF + q * 256), 16,
-                                                         p < NPAIR ? u_src + p * u_pair + term * u_term + jt * 1024 : OOB, 0, 0, 0);
+                const int src = p < NPAIR ? u_src + p * u_pair + term * u_term + jt * 1024 : OOB;
+                if constexpr (DMA)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, LDS_PTR3(ulds + buf * UBUF + q * 256), 16, src, 0, 0, 0);
+                else
+                    ust[k] = __builtin_amdgcn_raw_buffer_load_b128(ur, src, 0, 0);
+            }
+        }
+    };
+    auto commit = [&](int buf) {                        // DMA = false: registers -> LDS (after the loads have landed)
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int q = wave + 8 * k;
+                if (q < 42) *reinterpret_cast<i32x4 *>(ulds + buf * UBUF + q * 256 + lane * 4) = ust[k];
             }
         }
     };
@@ -1377,6 +1392,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dma(0, 0);
     load_v(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    commit(0);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
@@ -1409,6 +1425,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (p + 1 < NPAIR) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of pair p + 1 (and its V) have landed
+            commit(buf ^ 1);
             __syncthreads();                                     // ... everybody's have, and nobody reads this buffer any more
         }
     }
@@ -1466,6 +1483,14 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
                 (void)hipGetLastError();
                 return DECNET_ERR_UNSUPPORTED;
             }
+            if (use_lds == 2) {
+                if (hipFuncSetAttribute((const void *)wino_gemm_bf16x3_lds<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return DECNET_ERR_UNSUPPORTED;
+                }
+                hipLaunchKernelGGL((wino_gemm_bf16x3_lds<7, false>), dim3(ceil_div(nt, 192), np), dim3(512), lds, s, V, Ub, M, nt,
+                                   Ci, Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
+            } else
             hipLaunchKernelGGL((wino_gemm_bf16x3_lds<7>), dim3(ceil_div(nt, 192), np), dim3(512), lds, s, V, Ub, M, nt, Ci,
                                Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
             return decnet_launch_status();
