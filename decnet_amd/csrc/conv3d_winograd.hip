@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void wino_output_transform(
 // (tile, channel), LDS instead of x.
 constexpr int MID_THREADS = 512;
 
-template <int HALF>
+template <int HALF, int NCH = 4>
 __device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __amdgpu_buffer_rsrc_t vr, int voff, int xs,
                                                const Tiling &g, int Wp, int ch, int z0, int y0, int x0) {
     constexpr int T = 6, KW = 3, K0 = HALF * KW;
@@ -501,7 +501,7 @@ __device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __a
         for (int jj = 0; jj < T; ++jj) {
             const int y = y0 - 1 + jj;
             const bool okzy = (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H;
-            const float *row = ys + ((okzy ? z * g.H + y : 0) * 4 + ch) * Wp;
+            const float *row = ys + ((okzy ? z * g.H + y : 0) * NCH + ch) * Wp;
             float r[T];
 #pragma unroll
             for (int k = 0; k < T; ++k) {
@@ -550,17 +550,19 @@ __device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __a
 // Phase 1 of wino_mid_transform / wino_tail_transform: the sample's M tiles of four channels -> y = relu(A^T M A * scale +
 // shift) (+ what the LDS volume held before: the preloaded residual) into the LDS volume [D][H][4][Wp].  A^T along W and H
 // per depth plane of M, the D pass as an accumulation; one thread per (tile, channel), two planes of M in flight.
+// NCH channels c0 .. c0 + NCH - 1 of the quad (4, or 2 for the half-quad workgroups of wino_mid_transform2), NTHR threads.
+template <int NCH = 4, int NTHR = MID_THREADS>
 __device__ __forceinline__ void wino_output_phase(__amdgpu_buffer_rsrc_t mr, float *__restrict__ ys, const Tiling &g, int Wp,
                                                   int cq, int b, int nts, int nt, int xs, const float *__restrict__ scale,
-                                                  const float *__restrict__ shift, int C, int relu, bool res_in) {
+                                                  const float *__restrict__ shift, int C, int relu, bool res_in, int c0 = 0) {
     constexpr int T = 6, O = 4;
-    const int items = nts * 4;
-    for (int it = threadIdx.x; it < items; it += MID_THREADS) {
-        const int ch = it & 3, tl = it >> 2;
-        const int co = cq * 4 + ch;
+    const int items = nts * NCH;
+    for (int it = threadIdx.x; it < items; it += NTHR) {
+        const int ch = it % NCH, tl = it / NCH;
+        const int co = cq * 4 + c0 + ch;
         int bb, z0, y0, x0;
         tile_coords<O, O, O>(tl, g, bb, z0, y0, x0);
-        const int moff = ((cq * nt + b * nts + tl) * 4 + ch) * 4;
+        const int moff = ((cq * nt + b * nts + tl) * 4 + c0 + ch) * 4;
         float acc[O][O][O];
 #pragma unroll
         for (int i = 0; i < O; ++i)
@@ -621,7 +623,7 @@ __device__ __forceinline__ void wino_output_phase(__amdgpu_buffer_rsrc_t mr, flo
 #pragma unroll
             for (int jj = 0; jj < O; ++jj) {
                 const int z = z0 + i, yy = y0 + jj;
-                float *row = ys + ((z * g.H + yy) * 4 + ch) * Wp + x0;
+                float *row = ys + ((z * g.H + yy) * NCH + ch) * Wp + x0;
 #pragma unroll
                 for (int k = 0; k < O; ++k) {
                     if (z < g.D && yy < g.H && x0 + k < g.W) {
@@ -682,6 +684,56 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
         else mid_input_half<1>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
     }
 #endif
+}
+
+// The same with HALF a quad per workgroup (two channels, 256 threads, 46 KB of LDS): two workgroups per CU, so one's
+// loads (phase 1) run beside the other's stores (phase 2), and 864 half-size workgroups pack the CUs better than 432 (the
+// second, 69 %-full round of the 512-thread kernel costs a whole one).  The two halves of a quad touch the same 16-byte
+// groups of M and V (8 bytes each): block ids i and i + 8 are the partners -- the same XCD, dispatched back to back -- so
+// that they meet in that XCD's L2.  R is [sample][quad][half][D][H][2][Wp] here.
+constexpr int MID2_THREADS = 256;
+__global__ __launch_bounds__(MID2_THREADS) void wino_mid_transform2(
+    const float *__restrict__ M, float *__restrict__ V, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ res_in, float *__restrict__ res_out, Tiling g,
+    int C, int nt, int relu, int units) {
+    extern __shared__ float ys[];                       // [D][H][2][Wp]
+    constexpr int O = 4, NCH = 2;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, h = k & 1, unit = (k >> 1) * 8 + xcd;
+    if (unit >= units) return;
+    const int Wp = g.W | 1, vol = g.D * g.H * NCH * Wp;
+    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;
+    const int b = unit / nq, cq = unit - b * nq, c0 = 2 * h;
+    const int nts = g.Td * g.Th * g.Tw, items = nts * NCH;
+    const int xs = Q * nt * 16;
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, 216 * xs, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, 216 * xs, 0x00020000);
+    const size_t blk = ((size_t)unit * 2 + h) * vol;
+    if (res_in) {
+        for (int i = threadIdx.x * 4; i < vol; i += MID2_THREADS * 4) {
+            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(ys + i) = *reinterpret_cast<const f32x4 *>(res_in + blk + i);
+            else for (int e = i; e < vol; ++e) ys[e] = res_in[blk + e];
+        }
+        __syncthreads();
+    }
+    wino_output_phase<NCH, MID2_THREADS>(mr, ys, g, Wp, cq, b, nts, nt, xs, scale, shift, C, relu, res_in != nullptr, c0);
+    __syncthreads();
+    if (res_out) {
+        for (int i = threadIdx.x * 4; i < vol; i += MID2_THREADS * 4) {
+            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(res_out + blk + i) = *reinterpret_cast<const f32x4 *>(ys + i);
+            else for (int e = i; e < vol; ++e) res_out[blk + e] = ys[e];
+        }
+    }
+    const int itp = (items + 63) & ~63;
+    for (int it = threadIdx.x; it < 2 * itp; it += MID2_THREADS) {
+        const int half = it >= itp, id = it - half * itp;
+        if (id >= items) continue;
+        const int ch = id % NCH, tl = id / NCH;
+        int bb, z0, y0, x0;
+        tile_coords<O, O, O>(tl, g, bb, z0, y0, x0);
+        const int voff = ((cq * nt + b * nts + tl) * 4 + c0 + ch) * 4;
+        if (half == 0) mid_input_half<0, NCH>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
+        else mid_input_half<1, NCH>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
+    }
 }
 
 // ---- output transform of the LAST C -> C layer + the 216 -> 1 convolution (submodule.py:648, 661) ----
@@ -1644,6 +1696,18 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
             hipLaunchKernelGGL((wino_output_transform<6, 6, 6, 1>), dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, s,
                                M, scale[i], shift[i], (const float *)nullptr, y, g, C, 1, 0, nt, bytes);
         } else {
+            static const int mid2 = [] { const char *e = getenv("DECNET_WINO_MID"); return e && atoi(e) == 2; }();
+            if (mid2) {                                 // half a quad per workgroup (measured alternative)
+                const int units = B * ((C + 3) / 4);
+                if (lds / 2 > 64 * 1024 &&
+                    hipFuncSetAttribute((const void *)wino_mid_transform2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return DECNET_ERR_UNSUPPORTED;
+                }
+                hipLaunchKernelGGL(wino_mid_transform2, dim3((unsigned)(16 * ceil_div(units, 8))), dim3(MID2_THREADS), lds / 2, s,
+                                   M, V, scale[i], shift[i], i == res_dst ? R : (const float *)nullptr,
+                                   i == res_src ? R : (float *)nullptr, g, C, nt, 1, units);
+            } else
             hipLaunchKernelGGL(wino_mid_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), lds, s, M, V,
                                scale[i], shift[i], i == res_dst ? R : (const float *)nullptr,
                                i == res_src ? R : (float *)nullptr, g, C, nt, 1);
