@@ -220,3 +220,23 @@ def test_last_unit_and_softargmax_behind_the_stack(dev, B, H, W, D):
                                                       ws.data_ptr(), B, C, H, W, D, 2, None), "fused tail, no reg")
     torch.cuda.synchronize()
     assert torch.equal(pred1, pred2)
+
+
+@pytest.mark.parametrize("env", [{"DECNET_WINO_MID": "2"}, {"DECNET_WINO_GEMM_LDS": "1"}, {"DECNET_WINO_GEMM_LDS": "2"},
+                                 {"DECNET_WINO_TM": "6"}, {"DECNET_WINO_TM": "2"}, {"DECNET_WINO_TAIL": "1"},
+                                 {"DECNET_WINO_STACK": "0"}, {"DECNET_WINO_HEAD": "0"}])
+def test_measured_alternatives_stay_correct(env):
+    """The opt-in variants DESIGN.md quotes numbers for (half-quad mid kernel, LDS-shared GEMMs, the two re-tilings, the last
+    unit behind the stack) and the switches back to the unfused paths: the stack cases of this file and the stage-0 golden /
+    single-entry cases under each of them (the switches are read once per process: child processes)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    e = dict(os.environ, **env)
+    files = [os.path.join(here, "test_stage0_gpu.py")]
+    if "DECNET_WINO_STACK" not in env and "DECNET_WINO_HEAD" not in env:    # (those two switch the entries of this file off)
+        files.append(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k",
+                        "matches_layer or float64 or on_chip or behind_the_stack or golden or single_c_entry"],
+                       env=e, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
