@@ -170,7 +170,7 @@ def test_mixed_row_densities_sparse_kernel_and_handover(dev, C, W, D):
     L = torch.relu(torch.randn(1, C, H, W, generator=g))
     R = torch.relu(torch.randn(1, C, H, W, generator=g))
     dens = [(0.02, 0.02), (1.0, 1.0), (0.1, 0.1), (0.5, 0.5), (0.05, 0.9), (0.9, 0.05), (0.2, 0.2),
-            (0.0, 0.3), (0.3, 0.0), (0.26, 0.26), (0.03, 0.03), (0.03, 0.03)]
+            (0.0, 0.3), (0.3, 0.0), (0.26, 0.26), (0.6, 0.6), (0.03, 0.03)]    # 0.6: > 512 active pixels per side, < 45 % of the pairs
     rm = torch.stack([(torch.rand(W, generator=g) < p).float() for p, _ in dens]).view(1, H, W)
     tm = torch.stack([(torch.rand(W, generator=g) < p).float() for _, p in dens]).view(1, H, W)
     tm[0, 10, 100:300] = 1.0                       # cluster: 200 consecutive active right pixels
@@ -409,3 +409,16 @@ def test_mask_kernel_bits_feed_the_bit_mask_call(dev):
     assert bits is not None and bits.dtype == torch.int64 and tuple(bits.shape) == (2, 66, 3)
     assert torch.equal(pack_mask_bits(m), bits.cpu())
     assert 0.2 < float(m.mean()) < 0.8
+
+
+@pytest.mark.parametrize("env", [{"DECNET_SPAMAT_MID": "1"}, {"DECNET_SPAMAT_MID": "0"}, {"DECNET_SPAMAT_SPARSE_PCT": "35"}])
+def test_mid_density_switches(env):
+    """Rows of 257 - 640 active pixels per side under the other settings of their path (own 256-thread launch; off: the band
+    kernel's compact / dense paths; the round-2 threshold): the mixed-density and randomized cases in a child process each
+    (the switches are read once per process)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "mixed_row_densities or randomized_shapes or bit_packed"], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
