@@ -995,8 +995,22 @@ __device__ __forceinline__ int sparse_row_body(
     const float *rrow = tar + ((size_t)b * C * H + y) * W;
     const float *trow = tmask + rowpix, *mrow = rmask + rowpix;
 
-    // ---- 1. masks -> bits, counts
+    // ---- 0. (mid-density body) the features of ALL of this thread's pixels are requested with the masks: at 25 - 65 %
+    // activity a gather of the active pixels behind the index lists touches nearly every sector anyway, and it is a
+    // second, dependent memory round trip.  The 256-slot kernel keeps the gather: sparse rows never fetch inactive lines.
+    constexpr bool ALL = CAP > 256 && PPT == 4;
     const int p4 = tid * PPT;                        // this thread's PPT consecutive pixels
+    float4 lv[ALL ? CQ : 1], rv[ALL ? CQ : 1];
+    if constexpr (ALL) {
+        const bool alf = ((W & 3) == 0) && ((((uintptr_t)lrow) | ((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            const bool ok = p4 < W && c < C;
+            lv[c] = ok ? load4(lrow + (size_t)c * plane, p4, W, alf) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[c] = ok ? load4(rrow + (size_t)c * plane, p4, W, alf) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // ---- 1. masks -> bits, counts
     int fr = 0, fl = 0;
     {
         const bool alm = ((W & 3) == 0) && ((((uintptr_t)trow) | ((uintptr_t)mrow)) & 15) == 0;
@@ -1036,20 +1050,43 @@ __device__ __forceinline__ int sparse_row_body(
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             RK[p4 + k] = er;
-            if (fr & (1 << k)) XR[er++] = p4 + k;
+            if (fr & (1 << k)) {
+                if constexpr (ALL) {
+#pragma unroll
+                    for (int c = 0; c < CQ; ++c)
+                        RF[c * SP_FP_ + er] = k == 0 ? rv[c].x : k == 1 ? rv[c].y : k == 2 ? rv[c].z : rv[c].w;
+                }
+                XR[er++] = p4 + k;
+            }
             RKL[p4 + k] = el;
-            if (fl & (1 << k)) XL[el++] = p4 + k;
+            if (fl & (1 << k)) {
+                if constexpr (ALL) {
+#pragma unroll
+                    for (int c = 0; c < CQ; ++c)
+                        LF[c * SP_FP_ + el] = k == 0 ? lv[c].x : k == 1 ? lv[c].y : k == 2 ? lv[c].z : lv[c].w;
+                }
+                XL[el++] = p4 + k;
+            }
         }
         if (tid == 0) { RK[NPX] = nR; RKL[NPX] = nL; }
         if (tid < 16) XR[nR + tid] = 1 << 20;           // padding of the last tile: d < 0, out of range
+        if constexpr (ALL) {                            // the slots behind the last active pixel read as zeros
+            if (tid < 32) {
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) {
+                    if (nR + tid < SP_FP_) RF[c * SP_FP_ + nR + tid] = 0.f;
+                    if (nL + tid < SP_FP_) LF[c * SP_FP_ + nL + tid] = 0.f;
+                }
+            }
+        }
     }
     __syncthreads();
 
     // ---- 2. features of the active pixels (loads first, LDS stores after the span selection)
     constexpr int SPT = (CAP + NTHR - 1) / NTHR;       // slots per thread (1, or 2 for the 256-thread mid-density kernel)
-    float rf[SPT][CQ], lf[SPT][CQ];
+    float rf[ALL ? 1 : SPT][CQ], lf[ALL ? 1 : SPT][CQ];
 #pragma unroll
-    for (int u = 0; u < SPT; ++u) {
+    for (int u = 0; u < (ALL ? 0 : SPT); ++u) {
         const int slot = tid + u * NTHR;
         const int xr_own = slot < nR ? XR[slot] : -1, xl_own = slot < nL ? XL[slot] : -1;
 #pragma unroll
@@ -1071,19 +1108,21 @@ __device__ __forceinline__ int sparse_row_body(
         }
         if (__syncthreads_or(bad)) return 2;            // nothing written yet; more tiles per chunk may do
     }
+    if constexpr (!ALL) {
 #pragma unroll
-    for (int c = 0; c < CQ; ++c) {
+        for (int c = 0; c < CQ; ++c) {
 #pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const int slot = tid + u * NTHR;
-            if (slot < CAP) {
-                RF[c * SP_FP_ + slot] = rf[u][c];        // slots >= nR hold zeros
-                LF[c * SP_FP_ + slot] = lf[u][c];
+            for (int u = 0; u < SPT; ++u) {
+                const int slot = tid + u * NTHR;
+                if (slot < CAP) {
+                    RF[c * SP_FP_ + slot] = rf[u][c];    // slots >= nR hold zeros
+                    LF[c * SP_FP_ + slot] = lf[u][c];
+                }
             }
+            if (tid < 16) RF[c * SP_FP_ + CAP + tid] = 0.f;
         }
-        if (tid < 16) RF[c * SP_FP_ + CAP + tid] = 0.f;
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- 3. matching
     const int j = lane & 15, q = lane >> 4;
