@@ -422,3 +422,28 @@ def test_mid_density_switches(env):
                         "mixed_row_densities or randomized_shapes or bit_packed"], env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_randomized_densities_around_the_path_boundaries(dev):
+    """130 random (C, H, W, D, left / right density) cases with the densities that decide a row's path (sparse-row kernel
+    <= 256 active pixels, the 640-slot body, compact, dense): fused forward against the oracle."""
+    import decnet_amd
+    for seed in range(200, 330):
+        rng = np.random.default_rng(seed)
+        C = int(rng.choice([8, 8, 8, 24, 72]))
+        W = int(rng.integers(40, 1000)) if C == 8 else int(rng.integers(40, 400))
+        D = int(rng.integers(3, min(W, 230)))
+        H = int(rng.integers(1, 4))
+        pr, pt = [float(rng.choice([0.05, 0.2, 0.3, 0.45, 0.6, 0.7, 1.0])) for _ in range(2)]
+        g = torch.Generator().manual_seed(seed)
+        L = torch.relu(torch.randn(1, C, H, W, generator=g))
+        R = torch.relu(torch.randn(1, C, H, W, generator=g))
+        rm = (torch.rand(1, H, W, generator=g) < pr).float()
+        tm = (torch.rand(1, H, W, generator=g) < pt).float()
+        o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+        v, _, _ = oracle.spavar_forward(L, R, rm, tm, o, D)
+        fo, fv, fs, fm = decnet_amd.spamatvar_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
+        tag = str(dict(seed=seed, C=C, H=H, W=W, D=D, pr=pr, pt=pt))
+        np.testing.assert_allclose(fo.cpu().numpy(), o, rtol=1e-5, atol=3e-4, err_msg=tag)
+        np.testing.assert_allclose(fs.cpu().numpy(), s, rtol=2e-5, atol=1e-9, err_msg=tag)
+        np.testing.assert_allclose(fv.cpu().numpy(), v, rtol=2e-4, atol=2e-2, err_msg=tag)
