@@ -874,10 +874,21 @@ __global__ __launch_bounds__(MID_THREADS) void wino_head_transform(
     float *ty = tx + 3 * (W + D);                        // [H][3]: y0, wy0, wy1
     const int nch = C - cq * 4 < 4 ? C - cq * 4 : 4;
     const size_t src = ((size_t)b * C + cq * 4) * plane; // the four channel planes are contiguous in NCHW
-    for (int i = threadIdx.x; i < 4 * plane; i += MID_THREADS) {
-        const bool ok = i < nch * plane;
-        Ls[i] = ok ? left[src + i] : 0.f;
-        Rs[i] = ok ? right[src + i] : 0.f;
+    // (eight positions per pass: their sixteen loads are in flight together instead of one round trip per position)
+    for (int i0 = threadIdx.x; i0 < 4 * plane; i0 += 8 * MID_THREADS) {
+        float lv[8], rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * MID_THREADS;
+            const bool ok = i < nch * plane;
+            lv[u] = ok ? left[src + i] : 0.f;
+            rv[u] = ok ? right[src + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * MID_THREADS;
+            if (i < 4 * plane) { Ls[i] = lv[u]; Rs[i] = rv[u]; }
+        }
     }
     for (int i = threadIdx.x; i < W + D; i += MID_THREADS) {
         const int xd = i - (D - 1);                      // x - d
