@@ -423,14 +423,14 @@ def e2e_bench(B, dev, iters=5):
 
 def train_leg(dev, B=4, iters=30):
     """BASELINE config 5 (per-GPU share: 4 pairs of 972x540): SpaMat forward + backward at stages 1-3, mask
-    densities 1.0 and 0.1.  Kernel times: the C-ABI entry points on preallocated buffers (events over
+    densities 1.0, 0.5 and 0.1.  Kernel times: the C-ABI entry points on preallocated buffers (events over
     back-to-back launches); step time: the same through SpaMatFunction.apply / .backward (allocations and
     autograd included, no host sync inside the loop).  Backward bytes: 4*B*H*W*(4C + 6)."""
     import decnet_amd
     from decnet_amd import ops
     mod = decnet_amd.SpaMat()
     res = []
-    for dens in (1.0, 0.1):
+    for dens in (1.0, 0.5, 0.1):
         feats, masks = make_inputs(B, dev, dens, seed=555)
         row = {"mask_density": dens, "stages": []}
         step_ms = 0.0

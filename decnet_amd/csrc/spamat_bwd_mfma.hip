@@ -349,7 +349,16 @@ int launch_side(const float *ref, const float *tar, const float *rmask, const fl
 // Nothing is kept per tile, so there is no limit on the number of tiles of a window.  Rows with more
 // active pixels are left to the band kernels: BWD_MARK is written into channel 0 of both gradients
 // at the first pixel of each of their segments (seg_w0 / seg_w1 pixels wide).
-constexpr int SB_THREADS = 256, SB_NWAVE = SB_THREADS / 64, SB_CAP = 256, SB_LP = SB_CAP + 16, SB_FP = 324;
+// Two instantiations: (CAP 256, 256 threads: up to six workgroups per CU, the sparse regime) and, round 3, (CAP 640, 512
+// threads, MID: only the rows the first one marked) for the rows of 257 - 640 active pixels per side, which before fell onto
+// the two band launches at the cost of dense rows (stage 3, density 0.5: 0.74 ms, the same as density 1.0).
+constexpr int SB_THREADS = 256, SB_CAP = 256, SBM_THREADS = 512, SBM_CAP = 640;
+__host__ __device__ constexpr int sb_lp(int cap) { return cap + 16; }
+__host__ __device__ constexpr int sb_fp(int cap) { return ((cap + 16 + 63) & ~63) + 4; }      // feature pitch == 4 (mod 64)
+__host__ __device__ constexpr size_t sb_words(int kq, int ppt, int cap, int nthr) {
+    return (size_t)2 * sb_lp(cap) + 2 * (size_t)(nthr * ppt / 2 + 2) + 16 + 4 * (size_t)sb_lp(cap) +
+           2 * (size_t)4 * kq * sb_fp(cap) + (size_t)(nthr / 64) * (4 * kq + 1) * 16;
+}
 
 __device__ __forceinline__ int wave_incl_scan_b(int v, int lane) {
 #pragma unroll
@@ -360,15 +369,16 @@ __device__ __forceinline__ int wave_incl_scan_b(int v, int lane) {
     return v;
 }
 
-template <bool VAR, int KQ, int PPT>
-__global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
+template <bool VAR, int KQ, int PPT, int CAP = SB_CAP, int NTHR = SB_THREADS, bool MID = false>
+__global__ __launch_bounds__(NTHR, (NTHR == 256 ? 4 : 2)) void spamat_bwd_sparse(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity,
     const float *__restrict__ out, const float *__restrict__ sum_sim,
     const float *__restrict__ max_cost, const float *__restrict__ grad_out,
     float *__restrict__ grad_ref, float *__restrict__ grad_tar, float *__restrict__ grad_disp, int C,
     int H, int W, int D, int seg_w0, int seg_w1) {
-    constexpr int CQ = 4 * KQ, NCB = (CQ + 15) / 16, NPX = SB_THREADS * PPT, RKW = NPX / 2 + 2;
+    constexpr int CQ = 4 * KQ, NCB = (CQ + 15) / 16, NPX = NTHR * PPT, RKW = NPX / 2 + 2;
+    constexpr int SB_NWAVE = NTHR / 64, SB_LP = sb_lp(CAP), SB_FP = sb_fp(CAP), SB_CAP = CAP, SB_THREADS = NTHR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // words: XR [LP] | XL [LP] | RK, RKL [(NPX+4) x u16] | WT [16] | NM, OUT, GS, MU [LP] | RF, LF [CQ][FP]
     constexpr int offXR = 0, offXL = SB_LP, offRK = 2 * SB_LP, offRKL = offRK + RKW, offWT = offRKL + RKW,
@@ -386,6 +396,9 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *SC = smem + offSC + wave * SCW;
     const int row = blockIdx.x, b = row / H, y = row - b * H;
+    if (MID) {      // only the rows the 256-slot launch left (BWD_MARK at the row's first pixel, channel 0 of grad_ref)
+        if (__float_as_int(grad_ref[((size_t)b * C * H + y) * W]) != BWD_MARK) return;
+    }
     const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
     const float *lrow = ref + ((size_t)b * C * H + y) * W;
     const float *rrow = tar + ((size_t)b * C * H + y) * W;
@@ -409,18 +422,20 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
     }
     const int cr = __popc(fr), cl = __popc(fl);
     const int ir = wave_incl_scan_b(cr, lane), il = wave_incl_scan_b(cl, lane);
-    if (lane == 63) { WT[wave] = ir; WT[4 + wave] = il; }
+    if (lane == 63) { WT[wave] = ir; WT[8 + wave] = il; }
     __syncthreads();
     int nR = 0, nL = 0, baseR = 0, baseL = 0;
 #pragma unroll
     for (int w = 0; w < SB_NWAVE; ++w) {
-        if (w < wave) { baseR += WT[w]; baseL += WT[4 + w]; }
+        if (w < wave) { baseR += WT[w]; baseL += WT[8 + w]; }
         nR += WT[w];
-        nL += WT[4 + w];
+        nL += WT[8 + w];
     }
     if (nL > SB_CAP || nR > SB_CAP) {                  // left to the band kernels (marker launches)
-        for (int x = tid * seg_w0; x < W; x += SB_THREADS * seg_w0) glrow[x] = __int_as_float(BWD_MARK);
-        for (int x = tid * seg_w1; x < W; x += SB_THREADS * seg_w1) grrow[x] = __int_as_float(BWD_MARK);
+        if (!MID) {                                     // (MID: the marks of the first launch stay)
+            for (int x = tid * seg_w0; x < W; x += SB_THREADS * seg_w0) glrow[x] = __int_as_float(BWD_MARK);
+            for (int x = tid * seg_w1; x < W; x += SB_THREADS * seg_w1) grrow[x] = __int_as_float(BWD_MARK);
+        }
         return;
     }
     {
@@ -442,27 +457,40 @@ __global__ __launch_bounds__(SB_THREADS, 4) void spamat_bwd_sparse(
 
     // ---- 2. gathers (all loads of a thread in flight), zero fill of the inactive pixels
     {
-        const int xr_own = tid < nR ? XR[tid] : -1, xl_own = tid < nL ? XL[tid] : -1;
-        float rf[CQ], lf[CQ];
+        constexpr int SPT = (SB_CAP + SB_THREADS - 1) / SB_THREADS;      // slots per thread (2 for the 640-slot launch)
+        float rf[SPT][CQ], lf[SPT][CQ], nm[SPT], oo[SPT], gs[SPT], mu[SPT];
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) {
-            rf[c] = (xr_own >= 0 && c < C) ? rrow[(size_t)c * plane + xr_own] : 0.f;
-            lf[c] = (xl_own >= 0 && c < C) ? lrow[(size_t)c * plane + xl_own] : 0.f;
-        }
-        float nm = 0.f, oo = 0.f, gs = 0.f, mu = 0.f;
-        if (xl_own >= 0) {
-            nm = -max_cost[rowpix + xl_own] * LOG2E;
-            oo = out[rowpix + xl_own];
-            gs = grad_out[rowpix + xl_own] / sum_sim[rowpix + xl_own];
-            if (VAR) mu = disparity[rowpix + xl_own];
+        for (int u = 0; u < SPT; ++u) {
+            const int slot = tid + u * SB_THREADS;
+            const int xr_own = slot < nR ? XR[slot] : -1, xl_own = slot < nL ? XL[slot] : -1;
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) {
+                rf[u][c] = (xr_own >= 0 && c < C) ? rrow[(size_t)c * plane + xr_own] : 0.f;
+                lf[u][c] = (xl_own >= 0 && c < C) ? lrow[(size_t)c * plane + xl_own] : 0.f;
+            }
+            nm[u] = oo[u] = gs[u] = mu[u] = 0.f;
+            if (xl_own >= 0) {
+                nm[u] = -max_cost[rowpix + xl_own] * LOG2E;
+                oo[u] = out[rowpix + xl_own];
+                gs[u] = grad_out[rowpix + xl_own] / sum_sim[rowpix + xl_own];
+                if (VAR) mu[u] = disparity[rowpix + xl_own];
+            }
         }
 #pragma unroll
-        for (int c = 0; c < CQ; ++c) {
-            RF[c * SB_FP + tid] = rf[c];                // slots >= nR / nL hold zeros
-            LF[c * SB_FP + tid] = lf[c];
+        for (int u = 0; u < SPT; ++u) {
+            const int slot = tid + u * SB_THREADS;
+            if (slot < SB_CAP) {
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) {
+                    RF[c * SB_FP + slot] = rf[u][c];    // slots >= nR / nL hold zeros
+                    LF[c * SB_FP + slot] = lf[u][c];
+                }
+                NM[slot] = nm[u]; OUT[slot] = oo[u]; GS[slot] = gs[u]; MU[slot] = mu[u];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CQ; ++c)
             if (tid < 16) { RF[c * SB_FP + SB_CAP + tid] = 0.f; LF[c * SB_FP + SB_CAP + tid] = 0.f; }
-        }
-        NM[tid] = nm; OUT[tid] = oo; GS[tid] = gs; MU[tid] = mu;
         if (tid < 16) { NM[SB_CAP + tid] = 0.f; OUT[SB_CAP + tid] = 0.f; GS[SB_CAP + tid] = 0.f; MU[SB_CAP + tid] = 0.f; }
     }
     __syncthreads();
@@ -613,8 +641,7 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
         if (!sparse_off && W <= 2048) {
             marker = 1;
             const int ppt = W <= 1024 ? 4 : 8;
-            const size_t slds = 4 * (size_t)(2 * SB_LP + 2 * (SB_THREADS * ppt / 2 + 2) + 16 + 4 * SB_LP +
-                                             2 * 4 * KQ * SB_FP + SB_NWAVE * (4 * KQ + 1) * 16);
+            const size_t slds = 4 * sb_words(KQ, ppt, SB_CAP, SB_THREADS);
             if (slds > 64 * 1024) {
                 hipError_t e = ppt == 4
                     ? hipFuncSetAttribute((const void *)spamat_bwd_sparse<VAR, KQ, 4>,
@@ -631,8 +658,25 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
                 hipLaunchKernelGGL((spamat_bwd_sparse<VAR, KQ, 8>), dim3((unsigned)(B * H)), dim3(SB_THREADS), slds,
                                    stream, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out,
                                    grad_ref, grad_tar, grad_disp, C, H, W, D, xt0 * 16, xt1 * 16);
-            const int rc = decnet_launch_status();
+            int rc = decnet_launch_status();
             if (rc) return rc;
+            // rows of 257 - 640 active pixels per side (C <= 8, whole rows of <= 1024 pixels): the same algorithm with
+            // 640 slots on 512 threads, on the marked rows only (DECNET_SPAMAT_MID=0 leaves them to the band launches)
+            static const int mid_off = [] { const char *e = getenv("DECNET_SPAMAT_MID"); return e && atoi(e) == 0; }();
+            if constexpr (KQ == 2) {
+                const size_t mlds = 4 * sb_words(KQ, 4, SBM_CAP, SBM_THREADS);
+                if (!mid_off && ppt == 4 && mlds <= DECNET_LDS_BYTES / 2) {
+                    if (mlds > 64 * 1024) {
+                        hipError_t e = hipFuncSetAttribute((const void *)spamat_bwd_sparse<VAR, KQ, 4, SBM_CAP, SBM_THREADS, true>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+                        if (e != hipSuccess) return (int)e;
+                    }
+                    hipLaunchKernelGGL((spamat_bwd_sparse<VAR, KQ, 4, SBM_CAP, SBM_THREADS, true>), dim3((unsigned)(B * H)),
+                                       dim3(SBM_THREADS), mlds, stream, ref, tar, rmask, tmask, disparity, out, sum_sim,
+                                       max_cost, grad_out, grad_ref, grad_tar, grad_disp, C, H, W, D, xt0 * 16, xt1 * 16);
+                    if ((rc = decnet_launch_status())) return rc;
+                }
+            }
         }
     }
     int rc = launch_side<NT, VAR, KQ, 0>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
