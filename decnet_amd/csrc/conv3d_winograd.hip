@@ -1840,7 +1840,8 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
                                      int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
                                      int variant, void *stream) {
     if (!left || !right || !u || !scale || !shift || !y || !workspace) return DECNET_ERR_NULL_POINTER;
-    if (B < 1 || D < 1 || H < 2 || W < 2 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    if (H < 2 || W < 2) return DECNET_ERR_UNSUPPORTED;   // the stretched warp of one row / column: per-layer path
     for (int i = 0; i < n_layers; ++i)
         if (!u[i] || !scale[i] || !shift[i]) return DECNET_ERR_NULL_POINTER;
     if ((res_src < 0) != (res_dst < 0)) return DECNET_ERR_BAD_SHAPE;
@@ -1863,7 +1864,8 @@ int decnet_costvol_wino_stack_softargmax(const float *left, const float *right, 
                                          float *pred, float *workspace, int B, int C, int H, int W, int D, int variant,
                                          void *stream) {
     if (!left || !right || !u || !scale || !shift || !w_last || !pred || !workspace) return DECNET_ERR_NULL_POINTER;
-    if (B < 1 || D < 1 || H < 2 || W < 2 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    if (H < 2 || W < 2) return DECNET_ERR_UNSUPPORTED;   // the stretched warp of one row / column: per-layer path
     for (int i = 0; i < n_layers; ++i)
         if (!u[i] || !scale[i] || !shift[i]) return DECNET_ERR_NULL_POINTER;
     if ((res_src < 0) != (res_dst < 0)) return DECNET_ERR_BAD_SHAPE;

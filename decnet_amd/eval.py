@@ -153,13 +153,7 @@ def test(args, model=None):
         (left, right, disparity, _image, lm1, lm2, lm3, rm1, rm2, rm3, ori_h, ori_w, names, n_disp) = collate(
             [dataset[i] for i in batches[bi]])
         with torch.no_grad():
-            # eval.py:173-174 sets model.max_disp = n_disp for Middlebury.  Only a sample that carries a real range
-            # overrides --max_disp (a pair directory without calib.txt and the .npy layout report n_disp <= 0), and the
-            # range is rounded up to the next multiple of 27 as demo.py:149-155 does, so that the per-stage ranges are
-            # max_disp / 27, / 9, / 3 exactly (the constructor's own assertion, SparseDenseNetRefinementMask.py:42)
-            nd = max(int(v) for v in n_disp)
-            model.max_disp = int(math.ceil(nd / 27.0) * 27) if nd > 0 else int(args.max_disp)
-            assert model.max_disp % 27 == 0, "max_disp must be a multiple of 27 (down_scale^(num_stage-1))"
+            model.max_disp = batch_max_disp(args.dataset, n_disp, args.max_disp)
             left, right, disparity = left.to(device), right.to(device), disparity.to(device)
             lms, rms = [m.to(device) for m in (lm1, lm2, lm3)], [m.to(device) for m in (rm1, rm2, rm3)]
             torch.cuda.synchronize()
@@ -181,14 +175,15 @@ def test(args, model=None):
     if coll:
         # the per-batch metrics of every rank, once, as one all-gather of a fixed-size tensor over RCCL
         nb = len(batches)
-        mine = torch.full((nb, 2), float("nan"), device=device, dtype=torch.float64)
+        mine = torch.zeros((nb, 3), device=device, dtype=torch.float64)    # (epe, loss_3, owned): a NaN metric stays a NaN
         for bi, epe, l3 in rec:
-            mine[bi, 0], mine[bi, 1] = epe, l3
-        allm = torch.empty((world, nb, 2), device=device, dtype=torch.float64)
+            mine[bi, 0], mine[bi, 1], mine[bi, 2] = epe, l3, 1.0
+        allm = torch.empty((world, nb, 3), device=device, dtype=torch.float64)
         torch.distributed.all_gather_into_tensor(allm, mine)
-        merged = torch.where(torch.isnan(allm), torch.zeros_like(allm), allm).sum(0).cpu()
-        have = (~torch.isnan(allm[..., 0])).any(0).cpu()
-        rec = [(bi, float(merged[bi, 0]), float(merged[bi, 1])) for bi in range(nb) if bool(have[bi])]
+        allm = allm.cpu()
+        owner = allm[..., 2].argmax(0)                                      # shard_range: exactly one owner per batch
+        have = allm[..., 2].sum(0) > 0
+        rec = [(bi, float(allm[owner[bi], bi, 0]), float(allm[owner[bi], bi, 1])) for bi in range(nb) if bool(have[bi])]
     if args.is_eval and rec:
         result = (float(np.mean([r[1] for r in rec])), float(np.mean([r[2] for r in rec])))
         if rank == 0:
@@ -199,6 +194,25 @@ def test(args, model=None):
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return result
+
+
+def batch_max_disp(dataset, n_disp, default):
+    """The disparity range a batch runs with.
+    * MiddleburyMask: eval.py:173-175 sets ``model.max_disp = int(n_disp)`` UNROUNDED (the per-stage ranges are then the
+      floor divisions of SparseDenseNetRefinementMask.py:124 and the metric mask is gt < n_disp, modules/loss.py:427-437).
+      The reference runs that dataset at batch size 1 (``int()`` of a one-element tensor); a batch whose samples disagree
+      is refused here instead of silently taking one of them.
+    * 'pairs' (demo.py's directory layout): a calib.txt range rounded up to a multiple of 27, demo.py:149-155.
+    * every other dataset: --max_disp (eval.py never touches it)."""
+    ds = dataset.lower()
+    nds = sorted({int(v) for v in n_disp})
+    if ds == "middleburymask":
+        if len(nds) != 1:
+            raise ValueError("MiddleburyMask batch with mixed n_disp %s: the reference evaluates it at --batch_size 1" % nds)
+        return nds[0] if nds[0] > 0 else int(default)
+    if ds == "pairs" and nds[-1] > 0:
+        return int(math.ceil(nds[-1] / 27.0) * 27)
+    return int(default)
 
 
 def main(argv=None):

@@ -5,8 +5,10 @@ and ``bench.py``'s ``cpu_baseline`` leg may import this package; nothing under
 ``decnet_amd/`` does (tests/test_no_oracle_in_product.py enforces it).
 
 * ``spamat_oracle.c``  literal C restatement of SM_kernel.cu / SV_kernel.cu
-  (see that file's header for the reference line map and the parity status:
-  "parity unpinned" by reference execution -- no nvcc, no reference tests).
+  (see that file's header for the reference line map).  Pinned by reference execution:
+  tests/golden/spamat_ref_*.npz are outputs of the reference's own kernels on an MI355X.
+* ``ref_build.sh`` / ``ref.py``  build (hipcc -x hip, unmodified sources, into oracle/_ref/) and
+  load the REFERENCE's own SpaMat / SpaVar extensions; GPU only.
 * ``stage0.py``        torch-CPU restatement of the stage-0 dense path
   (submodule.py:389-390, 479-522, 608-662, 766-777), pinned by golden vectors
   generated from the imported reference (tests/golden/make_golden.py).
@@ -21,6 +23,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 _F = ctypes.POINTER(ctypes.c_float)
+
+
+def build_ref(force=False, reference="/root/reference"):
+    """oracle/_ref/SpaMat.so, SpaVar.so from the reference's own sources (oracle/ref_build.sh); only where the
+    reference tree exists (the build container) -- the GPU box uses the prebuilt files.  -> True if present."""
+    outs = [os.path.join(_HERE, "_ref", n) for n in ("SpaMat.so", "SpaVar.so")]
+    if os.path.isdir(os.path.join(reference, "modules", "SparseMatching", "src")) and \
+            (force or not all(os.path.exists(o) for o in outs)):
+        subprocess.check_call([os.path.join(_HERE, "ref_build.sh")], env=dict(os.environ, DECNET_REFERENCE=reference))
+    return all(os.path.exists(o) for o in outs)
 
 
 def build(force=False):

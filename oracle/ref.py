@@ -1,0 +1,77 @@
+"""oracle/ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Loader for the REFERENCE's own SpaMat / SpaVar extensions as built, unmodified, for gfx950 by
+oracle/ref_build.sh (oracle/_ref/SpaMat.so, SpaVar.so; pybind modules of
+modules/SparseMatching/src/SM_cuda.cpp:29-33 and modules/SparseVar/src/SV_cuda.cpp:34-38).
+They need a GPU to run; the calling protocol below is the one of the reference's
+functions/SpaMat.py:25-28,42-45 and functions/SpaVar.py:25-28,43-47 (caller allocates and
+zero-fills every output; the kernels run on the legacy default stream).
+"""
+import importlib.machinery
+import importlib.util
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(_HERE, "_ref")
+_MODS = {}
+
+
+def available():
+    return all(os.path.exists(os.path.join(REF_DIR, n + ".so")) for n in ("SpaMat", "SpaVar"))
+
+
+def _mod(name):
+    if name not in _MODS:
+        import torch  # noqa: F401  (libtorch must be mapped before the extension)
+        path = os.path.join(REF_DIR, name + ".so")
+        loader = importlib.machinery.ExtensionFileLoader(name, path)
+        spec = importlib.util.spec_from_loader(name, loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+        _MODS[name] = mod
+    return _MODS[name]
+
+
+def _sync_in(t):
+    """The reference launches on the legacy default stream: make the inputs visible to it."""
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
+
+
+def spamat_forward(L, R, rm, tm, max_disp):
+    """-> (output, sum_similarities, max_cost) on the device of L."""
+    import torch
+    _sync_in(L)
+    out, ssum, mx = (torch.zeros_like(rm) for _ in range(3))
+    torch.cuda.synchronize()
+    assert _mod("SpaMat").sparse_matching_cuda_forward(L, R, rm, tm, out, ssum, mx, int(max_disp)) == 1
+    torch.cuda.synchronize()
+    return out, ssum, mx
+
+
+def spamat_backward(L, R, rm, tm, out, ssum, mx, g, max_disp):
+    import torch
+    gl, gr = torch.zeros_like(L), torch.zeros_like(R)
+    torch.cuda.synchronize()
+    assert _mod("SpaMat").sparse_matching_cuda_backward(L, R, rm, tm, out, ssum, mx, g, gl, gr, int(max_disp)) == 1
+    torch.cuda.synchronize()
+    return gl, gr
+
+
+def spavar_forward(L, R, rm, tm, mu, max_disp):
+    import torch
+    out, ssum, mx = (torch.zeros_like(rm) for _ in range(3))
+    torch.cuda.synchronize()
+    assert _mod("SpaVar").sparse_var_cuda_forward(L, R, rm, tm, mu, out, ssum, mx, int(max_disp)) == 1
+    torch.cuda.synchronize()
+    return out, ssum, mx
+
+
+def spavar_backward(L, R, rm, tm, mu, out, ssum, mx, g, max_disp):
+    import torch
+    gl, gr, gd = torch.zeros_like(L), torch.zeros_like(R), torch.zeros_like(mu)
+    torch.cuda.synchronize()
+    assert _mod("SpaVar").sparse_var_cuda_backward(L, R, rm, tm, mu, out, ssum, mx, g, gl, gr, gd,
+                                                   int(max_disp)) == 1
+    torch.cuda.synchronize()
+    return gl, gr, gd

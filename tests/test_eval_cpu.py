@@ -4,6 +4,7 @@ import os
 import pickle
 
 import numpy as np
+import pytest
 import torch
 
 from decnet_amd import eval as dev_eval
@@ -109,3 +110,17 @@ def test_middlebury_pickle_layout(tmp_path):
 def test_parser_defaults_follow_eval_sh():
     a = dev_eval.build_parser().parse_args([])
     assert a.max_disp == 216 and a.base_channels == 8 and a.num_stage == 4 and a.gpus == 1
+
+
+def test_batch_max_disp_follows_each_callers_rule():
+    """eval.py:173-175 (Middlebury: int(n_disp), unrounded -> floor-divided per stage, …Mask.py:124),
+    demo.py:149-155 ('pairs': ceil to a multiple of 27), everything else keeps --max_disp."""
+    from decnet_amd.eval import batch_max_disp
+    assert batch_max_disp("MiddleburyMask", [290], 216) == 290
+    assert [290 // 3 ** k for k in (3, 2, 1, 0)] == [10, 32, 96, 290]
+    with pytest.raises(ValueError):
+        batch_max_disp("MiddleburyMask", [290, 145], 216)
+    assert batch_max_disp("pairs", [400, -1], 216) == 405
+    assert batch_max_disp("pairs", [-1, 0], 216) == 216
+    assert batch_max_disp("KITTI15Mask", [300], 216) == 216
+    assert batch_max_disp("SceneflowMask", [-1], 192) == 192
