@@ -34,7 +34,6 @@ SIGNATURES = {
     "decnet_conv3d_wino_stack_workspace_floats": [_I] * 6,
     "decnet_conv3d_wino_stack_bn_act": [_P] * 4 + [_I] * 3 + [_P] * 2 + [_I] * 6 + [_P],
     "decnet_costvol_wino_stack_bn_act": [_P] * 5 + [_I] * 3 + [_P] * 2 + [_I] * 6 + [_P],
-    "decnet_costvol_wino_stack_softargmax": [_P] * 5 + [_I] * 3 + [_P, _F, _F] + [_P] * 3 + [_I] * 6 + [_P],
     "decnet_conv3d_cout1_softargmax": [_P, _P, _F, _F, _P, _P] + [_I] * 5 + [_P],
     "decnet_conv2d_packed_floats": [_I] * 4,
     "decnet_conv2d_pack_weight": [_P, _P] + [_I] * 4 + [_P],
@@ -64,9 +63,6 @@ SIGNATURES = {
     "decnet_conv3d_cout1_workspace_floats": [_I] * 4,
     "decnet_conv3d_cout1_softargmax_ws": [_P, _P, _F, _F, _P, _P, _P] + [_I] * 5 + [_P],
     "decnet_disparity_regression": [_P] * 3 + [_I] * 4 + [_P],
-    "decnet_chain2d_packed_bytes": [_I, _I],
-    "decnet_chain2d_pack_weight": [_P, _P, _P, _I, _I, _I, _P],
-    "decnet_chain2d_forward": [_P, _P],
     "decnet_stage0_workspace_floats": [_I] * 6,
     "decnet_stage0_forward": [_P] * 6 + [_I] * 6 + [_P],
     "decnet_ncdhw_to_ndhwc": [_P, _P] + [_I] * 5 + [_P],

@@ -547,7 +547,7 @@ __device__ __forceinline__ void mid_input_half(const float *__restrict__ ys, __a
     }
 }
 
-// Phase 1 of wino_mid_transform / wino_tail_transform: the sample's M tiles of four channels -> y = relu(A^T M A * scale +
+// Phase 1 of wino_mid_transform: the sample's M tiles of four channels -> y = relu(A^T M A * scale +
 // shift) (+ what the LDS volume held before: the preloaded residual) into the LDS volume [D][H][4][Wp].  A^T along W and H
 // per depth plane of M, the D pass as an accumulation; one thread per (tile, channel), two planes of M in flight.
 // NCH channels c0 .. c0 + NCH - 1 of the quad (4, or 2 for the half-quad workgroups of wino_mid_transform2), NTHR threads.
@@ -684,172 +684,6 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
         else mid_input_half<1>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
     }
 #endif
-}
-
-// The same with HALF a quad per workgroup (two channels, 256 threads, 46 KB of LDS): two workgroups per CU, so one's
-// loads (phase 1) run beside the other's stores (phase 2), and 864 half-size workgroups pack the CUs better than 432 (the
-// second, 69 %-full round of the 512-thread kernel costs a whole one).  The two halves of a quad touch the same 16-byte
-// groups of M and V (8 bytes each): block ids i and i + 8 are the partners -- the same XCD, dispatched back to back -- so
-// that they meet in that XCD's L2.  R is [sample][quad][half][D][H][2][Wp] here.
-constexpr int MID2_THREADS = 256;
-__global__ __launch_bounds__(MID2_THREADS) void wino_mid_transform2(
-    const float *__restrict__ M, float *__restrict__ V, const float *__restrict__ scale,
-    const float *__restrict__ shift, const float *__restrict__ res_in, float *__restrict__ res_out, Tiling g,
-    int C, int nt, int relu, int units) {
-    extern __shared__ float ys[];                       // [D][H][2][Wp]
-    constexpr int O = 4, NCH = 2;
-    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, h = k & 1, unit = (k >> 1) * 8 + xcd;
-    if (unit >= units) return;
-    const int Wp = g.W | 1, vol = g.D * g.H * NCH * Wp;
-    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;
-    const int b = unit / nq, cq = unit - b * nq, c0 = 2 * h;
-    const int nts = g.Td * g.Th * g.Tw, items = nts * NCH;
-    const int xs = Q * nt * 16;
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, 216 * xs, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)V, 0, 216 * xs, 0x00020000);
-    const size_t blk = ((size_t)unit * 2 + h) * vol;
-    if (res_in) {
-        for (int i = threadIdx.x * 4; i < vol; i += MID2_THREADS * 4) {
-            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(ys + i) = *reinterpret_cast<const f32x4 *>(res_in + blk + i);
-            else for (int e = i; e < vol; ++e) ys[e] = res_in[blk + e];
-        }
-        __syncthreads();
-    }
-    wino_output_phase<NCH, MID2_THREADS>(mr, ys, g, Wp, cq, b, nts, nt, xs, scale, shift, C, relu, res_in != nullptr, c0);
-    __syncthreads();
-    if (res_out) {
-        for (int i = threadIdx.x * 4; i < vol; i += MID2_THREADS * 4) {
-            if (i + 4 <= vol) *reinterpret_cast<f32x4 *>(res_out + blk + i) = *reinterpret_cast<const f32x4 *>(ys + i);
-            else for (int e = i; e < vol; ++e) res_out[blk + e] = ys[e];
-        }
-    }
-    const int itp = (items + 63) & ~63;
-    for (int it = threadIdx.x; it < 2 * itp; it += MID2_THREADS) {
-        const int half = it >= itp, id = it - half * itp;
-        if (id >= items) continue;
-        const int ch = id % NCH, tl = id / NCH;
-        int bb, z0, y0, x0;
-        tile_coords<O, O, O>(tl, g, bb, z0, y0, x0);
-        const int voff = ((cq * nt + b * nts + tl) * 4 + c0 + ch) * 4;
-        if (half == 0) mid_input_half<0, NCH>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
-        else mid_input_half<1, NCH>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
-    }
-}
-
-// ---- output transform of the LAST C -> C layer + the 216 -> 1 convolution (submodule.py:648, 661) ----
-// The last unit (Conv3d(C, 1, 3) + BN) needs every channel of y at 27 taps; a workgroup here holds FOUR channels of a
-// sample (phase 1 above), so it forms ITS share of the 27-tap sum for every voxel out of LDS,
-//     part[b][quad][d][y][x] = sum_{c in quad} sum_tap w[c][tap] * y[c][d + dz][y + dy][x + dx],
-// and cout1_reduce_softargmax adds the C / 4 shares in a fixed order, applies the folded BN and the soft-argmax
-// (disparity_regression, submodule.py:766-777).  y of the last 216-channel layer is never written: 134 MB of M in,
-// 10 MB of partial sums out, instead of y out (40 MB), y in, tap products out and in.  MEASURED SLOWER than the three
-// kernels it replaces (72 + 6 us against 42 + 14 + 11 us at config 2: the tap loops are 108 dependent LDS / scalar-load
-// steps per output group on two waves per SIMD; with the weights in registers the kernel spills: 95 us), so
-// decnet_stage0_forward uses it only with DECNET_WINO_TAIL=1; the entry and its parity test stay.
-__global__ __launch_bounds__(MID_THREADS) void wino_tail_transform(
-    const float *__restrict__ M, const float *__restrict__ scale, const float *__restrict__ shift,
-    const float *__restrict__ w_last, float *__restrict__ part, Tiling g, int C, int nt, int relu) {
-    extern __shared__ float ys[];                       // [D][H][4][Wp]
-    const int D = g.D, H = g.H, W = g.W, Wp = W | 1, vol = D * H * 4 * Wp;
-    const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;
-    const int b = blockIdx.x / nq, cq = blockIdx.x - b * nq;
-    const int nts = g.Td * g.Th * g.Tw;
-    const int xs = Q * nt * 16;
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)M, 0, 216 * xs, 0x00020000);
-    // W even: the pad column x = W of every row (Wp = W + 1) is zeroed, so that x0 - 1 = -1 (the previous row's pad column;
-    // below the allocation for the very first row: LDS reads there return zero) and x0 + 4 = W read zeros without a test
-    const bool padded = (W & 1) == 0;
-    if (padded)
-        for (int r = threadIdx.x; r < D * H * 4; r += MID_THREADS) ys[r * Wp + W] = 0.f;
-    wino_output_phase(mr, ys, g, Wp, cq, b, nts, nt, xs, scale, shift, C, relu, false);
-    __syncthreads();
-    // a thread per four consecutive x of one (d, y): six values of every (tap row, channel) feed four outputs; the
-    // weights are uniform over the workgroup: scalar loads straight from w_last
-    const int gx = (W + 3) >> 2, ngr = D * H * gx;
-    float *out = part + ((size_t)b * nq + cq) * D * H * W;
-    const float *wq = w_last + (size_t)cq * 4 * 27;
-    const int nch = C - cq * 4 < 4 ? C - cq * 4 : 4;
-    for (int gi = threadIdx.x; gi < ngr; gi += MID_THREADS) {
-        const int x4 = gi % gx, zy = gi / gx, y = zy % H, z = zy / H, x0 = 4 * x4;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dz = 0; dz < 3; ++dz) {
-            const int zz = z + dz - 1;
-            if ((unsigned)zz >= (unsigned)D) continue;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int yy = y + dy - 1;
-                if ((unsigned)yy >= (unsigned)H) continue;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (c >= nch) break;
-                    const float *row = ys + ((zz * H + yy) * 4 + c) * Wp + x0 - 1;
-                    float v[6];
-                    if (padded) {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) v[k] = row[k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            const int xx = x0 - 1 + k;
-                            const float t = row[(unsigned)xx < (unsigned)W ? k : 1];
-                            v[k] = (unsigned)xx < (unsigned)W ? t : 0.f;
-                        }
-                    }
-                    const float *wr = wq + c * 27 + (dz * 3 + dy) * 3;
-                    const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(v[i + 2], w2, fmaf(v[i + 1], w1, fmaf(v[i], w0, acc[i])));
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (x0 + i < W) out[(size_t)zy * W + x0 + i] = acc[i];
-    }
-}
-
-// cost[b][d][y][x] = (sum over the quads' shares, in quad order) * scale + shift -> reg (optional) and the soft-argmax over d
-__global__ __launch_bounds__(256) void cout1_reduce_softargmax(const float *__restrict__ part, float scale, float shift,
-                                                               float *__restrict__ reg, float *__restrict__ pred,
-                                                               int B, int D, int H, int W, int nq, int PB) {
-    extern __shared__ float costs[];                   // [PB][D]
-    const int npix = B * H * W, plane = H * W;
-    const int d = threadIdx.x / PB, pl = threadIdx.x - d * PB;     // lanes along the pixels: coalesced shares
-    const int pix = blockIdx.x * PB + pl;
-    if (d < D && pix < npix) {
-        const int b = pix / plane, yx = pix - b * plane;
-        const float *p0 = part + ((size_t)b * nq * D + d) * plane + yx;
-        // six independent chains (q mod 6), combined in a fixed order: the loads of a chain step are in flight together
-        float a6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const size_t qs = (size_t)D * plane;
-        int q = 0;
-        for (; q + 6 <= nq; q += 6) {
-            float t[6];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) t[e] = p0[(size_t)(q + e) * qs];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) a6[e] += t[e];
-        }
-        for (int e = 0; q < nq; ++q, ++e) a6[e] += p0[(size_t)q * qs];
-        const float acc = ((a6[0] + a6[1]) + (a6[2] + a6[3])) + (a6[4] + a6[5]);
-        const float cost = fmaf(acc, scale, shift);
-        costs[pl * D + d] = cost;
-        if (reg) reg[((size_t)b * D + d) * plane + yx] = cost;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < PB && (int)(blockIdx.x * PB + threadIdx.x) < npix) {
-        float m = -INFINITY, S = 0.f, Tt = 0.f;
-        for (int dd = 0; dd < D; ++dd) {
-            const float cost = costs[threadIdx.x * D + dd];
-            const float mn = fmaxf(m, cost);
-            const float r = expf(m - mn), e = expf(cost - mn);       // m = -inf -> r = 0
-            S = fmaf(S, r, e);
-            Tt = fmaf(Tt, r, e * (float)dd);
-            m = mn;
-        }
-        pred[blockIdx.x * PB + threadIdx.x] = Tt / S;
-    }
 }
 
 // ---- cost volume + input transform of the first layer (the cost volume never reaches HBM) ----
@@ -1359,153 +1193,6 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3
     }
 }
 
-// The same product with the U^T terms shared through LDS.  tools: W3_ABLATE builds of the kernel above show what it
-// waits for -- not HBM and not the V split, but the number of operand REQUESTS per CU: with the U^T tiles always hitting
-// in L2 the time is unchanged (0.112 ms), with every other U^T tile load removed it is 0.090 ms, with none 0.060 ms.  In
-// the kernel above each U^T tile of a (point, k pair) is fetched by every wave that needs it (2 of the 4 waves of a
-// workgroup, all 8 row blocks).  Here a workgroup is 8 waves = 192 tiles x 224 co: the 42 KB of U^T terms of a k pair
-// come into LDS ONCE per workgroup by LDS-DMA (buffer_load ... lds, 16 bytes per lane: a wave-instruction moves the
-// 1 KB operand block of one (term, 16 co) so that every lane later reads ITS 16 bytes back with one ds_read_b128),
-// double buffered, one barrier per k pair; V stays register-direct.  Requests per 32 k and workgroup: 42 + 48 instead
-// of 2 x (84 + 24) for the same rows.
-#define LDS_PTR3(p) ((__attribute__((address_space(3))) void *)(p))
-// DMA = false: the workgroup's share of the U^T terms goes global -> registers (buffer_load_b128, 5 - 6 per wave) ->
-// ds_write_b128 instead of LDS-DMA (whose 16-byte form may cost the texture path as much as four dword loads).
-template <int NPAIR, bool DMA = true>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_bf16x3_lds(
-    const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
-    int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs) {
-    constexpr int TM = 3, TN = 7, OOB = 0x7fffffff, RING = 4, UBUF = 3 * 14 * 256;   // ints per LDS buffer (42 KB)
-    extern __shared__ __attribute__((aligned(16))) int ulds[];                       // [2][term][16-co tile][lane][4]
-    const int mblocks = gridDim.x, ngroups = gridDim.y;
-    int pt = blockIdx.y, mb = blockIdx.x;
-    if (swz) {
-        const int id = blockIdx.y * mblocks + blockIdx.x, per8 = 8 * mblocks;
-        const int r = id / per8, q = id - r * per8;
-        if (8 * (r + 1) <= ngroups) { pt = 8 * r + (q & 7); mb = q >> 3; }
-    }
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, kq = lane >> 4;
-    const int m0 = (mb * 4 + wm) * 48;                 // (waves past the last tile keep running on out-of-range rows:
-    const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;    // they take part in the copies and the barriers)
-    const int v_chunk = nt * 64, v_point = KC * v_chunk, m_point = CG * v_chunk;
-    const int u_term = W_BN * 64, u_pair = 3 * u_term, u_point = NPAIR * u_pair;
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * v_point, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ubb, 0, np * u_point, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * m_point, 0x00020000);
-    int v_row[TM], m_row[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + i * 16 + i16;
-        v_row[i] = m < nt ? m * v_ms : OOB;
-        m_row[i] = m < nt ? m * m_ms : OOB;
-    }
-    // copy q of a k pair = (term q / 14, 16-co tile q % 14): the lane's source is where it would load the operand from
-    const int u_src = i16 * 64 + kq * 16 + pt * u_point;
-    i32x4 ust[DMA ? 1 : 6];                            // DMA = false: this wave's copies in flight
-    auto dma = [&](int p, int buf) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int q = wave + 8 * k;
-            if (q < 42) {
-                const int term = q / 14, jt = q - term * 14;
-                const int src = p < NPAIR ? u_src + p * u_pair + term * u_term + jt * 1024 : OOB;
-                if constexpr (DMA)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, LDS_PTR3(ulds + buf * UBUF + q * 256), 16, src, 0, 0, 0);
-                else
-                    ust[k] = __builtin_amdgcn_raw_buffer_load_b128(ur, src, 0, 0);
-            }
-        }
-    };
-    auto commit = [&](int buf) {                        // DMA = false: registers -> LDS (after the loads have landed)
-        if constexpr (!DMA) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int q = wave + 8 * k;
-                if (q < 42) *reinterpret_cast<i32x4 *>(ulds + buf * UBUF + q * 256 + lane * 4) = ust[k];
-            }
-        }
-    };
-    f32x4 vf[TM][2];
-    i32x4 ub[RING][3], vs[TM][3];
-    auto read_u = [&](int slot, int buf, int j) {
-#pragma unroll
-        for (int term = 0; term < 3; ++term)
-            ub[slot][term] = *reinterpret_cast<const i32x4 *>(ulds + buf * UBUF + (term * 14 + wn * TN + j) * 256 + lane * 4);
-    };
-    auto load_v = [&](int p) {
-        const int vb = pt * v_point + kq * v_kqs;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = 2 * p + h;
-                const bool ok = p < NPAIR && v_row[i] != OOB && c * 16 + kq * 4 < Ci;
-                const i32x4 t = __builtin_amdgcn_raw_buffer_load_b128(vr, ok ? v_row[i] + vb + c * v_chunk : OOB, 0, 0);
-                vf[i][h] = f32x4{__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w)};
-            }
-    };
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int UT[6] = {2, 1, 0, 1, 0, 0}, VT[6] = {0, 1, 2, 0, 1, 0};
-
-    dma(0, 0);
-    load_v(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    commit(0);
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {
-        const int buf = p & 1;
-        if (p + 1 < NPAIR) dma(p + 1, buf ^ 1);         // the other buffer was last read before the previous barrier
-#pragma unroll
-        for (int i = 0; i < TM; ++i) split3(vf[i][0], vf[i][1], vs[i][0], vs[i][1], vs[i][2]);
-        load_v(p + 1);
-        read_u(0, buf, 0);
-        read_u(1, buf, 1);
-#pragma unroll
-        for (int g = 0; g < (TN + 1) / 2; ++g) {
-            const int j0 = 2 * g;
-            if (j0 + 2 < TN) read_u((j0 + 2) % RING, buf, j0 + 2);
-            if (j0 + 3 < TN) read_u((j0 + 3) % RING, buf, j0 + 3);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int j = j0 + jj;
-                        if (j < TN)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, ub[j % RING][UT[t]]),
-                                __builtin_bit_cast(bf16x8, vs[i][VT[t]]), acc[j][i], 0, 0, 0);
-                    }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (p + 1 < NPAIR) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of pair p + 1 (and its V) have landed
-            commit(buf ^ 1);
-            __syncthreads();                                     // ... everybody's have, and nobody reads this buffer any more
-        }
-    }
-    const int pb = pt * m_point + kq * m_kqs;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cg = wn * TN + j;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const f32x4 a = acc[j][i];
-            __builtin_amdgcn_raw_buffer_store_b128(
-                i32x4{__float_as_int(a[0]), __float_as_int(a[1]), __float_as_int(a[2]), __float_as_int(a[3])},
-                mr, cg < CG && m_row[i] != OOB ? m_row[i] + pb + cg * v_chunk : OOB, 0, 0);
-        }
-    }
-}
-
 // 1: bf16x3 GEMM (needs the split copy of U^T behind the fp32 one, see decnet_conv3d_wino_pack_weight).  The default
 // since round 3 (the same accuracy, 0.113 instead of 0.131 ms per layer at config 2); DECNET_WINO_GEMM=fp32 (or
 // static / any other value) selects the fp32 MFMA kernels.  Read once per process: it fixes the packed weights' size.
@@ -1517,11 +1204,8 @@ static int gemm_bf16x3() {
 template <int WM>
 int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                 hipStream_t stream, int v_shared = 0) {
-    static const int xg_env = [] { const char *e = getenv("DECNET_WINO_XG"); return e ? atoi(e) : 0; }();
-    int xg = 1;                                         // points per workgroup (experiments: 1 is best)
-    if (xg_env > 0 && np % xg_env == 0) xg = xg_env;
-    static const int swz_env = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
-    const int swz = (swz_env ? 1 : 0) | (v_shared ? 2 : 0);
+    const int xg = 1;                                   // points per workgroup (measured: 1 is best)
+    const int swz = 1 | (v_shared ? 2 : 0);             // XCD-aware block order on
     const dim3 grid(ceil_div(nt, WM * 48), np / xg), block(WM * 128);
     if (Ci == 216)
         hipLaunchKernelGGL((wino_gemm<WM, 13, 2>), grid, block, 0, stream, V, U, M, nt, Ci, Co, xg, np, swz);
@@ -1533,54 +1217,20 @@ int launch_gemm(const float *V, const float *U, float *M, int nt, int Ci, int Co
 // v_quad / m_quad: V / M in the quad-major layout (wino_gemm_bf16x3 only)
 int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int Co, int np,
                   hipStream_t s, int v_quad = 0, int m_quad = 0) {
-    static const int tile_env = [] { const char *e = getenv("DECNET_WINO_TILE"); return e ? atoi(e) : 0; }();
     if (gemm_bf16x3() && Ci == 216) {
-        static const int swz = [] { const char *e = getenv("DECNET_WINO_SWZ"); return e ? atoi(e) : 1; }();
+        constexpr int swz = 1;                          // XCD-aware block order
         const int *Ub = reinterpret_cast<const int *>(U + (size_t)np * pad16(Ci) * W_BN);   // split copy behind U^T
-        static const int tm = [] { const char *e = getenv("DECNET_WINO_TM"); return e ? atoi(e) : 3; }();
-        static const int use_lds = [] { const char *e = getenv("DECNET_WINO_GEMM_LDS"); return e ? atoi(e) : 0; }();
-        if (use_lds && tm == 3) {
-            constexpr int lds = 2 * 3 * 14 * 1024;
-            // (the attribute is per device: set per launch, it is cheap)
-            if (hipFuncSetAttribute((const void *)wino_gemm_bf16x3_lds<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-                (void)hipGetLastError();
-                return DECNET_ERR_UNSUPPORTED;
-            }
-            if (use_lds == 2) {
-                if (hipFuncSetAttribute((const void *)wino_gemm_bf16x3_lds<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return DECNET_ERR_UNSUPPORTED;
-                }
-                hipLaunchKernelGGL((wino_gemm_bf16x3_lds<7, false>), dim3(ceil_div(nt, 192), np), dim3(512), lds, s, V, Ub, M, nt,
-                                   Ci, Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
-            } else
-            hipLaunchKernelGGL((wino_gemm_bf16x3_lds<7>), dim3(ceil_div(nt, 192), np), dim3(512), lds, s, V, Ub, M, nt, Ci,
-                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
-            return decnet_launch_status();
-        }
-        if (tm == 6)        // one wave per SIMD, 96 tiles x 112 co per wave
-            hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7, 6>), dim3(ceil_div(nt, 192), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
-                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
-        else if (tm == 2)   // three waves per SIMD, 32 tiles x 112 co per wave
-            hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7, 2>), dim3(ceil_div(nt, 64), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
-                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
-        else if (tm == 61)  // the same, two-wave workgroups (96 tiles x 224 co)
-            hipLaunchKernelGGL((wino_gemm_bf16x3<1, 7, 6>), dim3(ceil_div(nt, 96), np), dim3(128), 0, s, V, Ub, M, nt, Ci,
-                               Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
-        else
         hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(nt, 96), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
                            Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
         return decnet_launch_status();
     }
     if (v_quad || m_quad) return DECNET_ERR_UNSUPPORTED;
     static const int gemm_static = [] { const char *e = getenv("DECNET_WINO_GEMM"); return e && !strcmp(e, "static") ? 1 : 0; }();
-    if (!gemm_static && !tile_env && Ci == 216 && np >= 8) {
+    if (!gemm_static && Ci == 216 && np >= 8) {
         hipLaunchKernelGGL((wino_gemm_persist<13, 2>), dim3(512), dim3(256), 0, s, V, U, M, nt, Ci, Co, np);
         return decnet_launch_status();
     }
-    return tile_env == 192 ? launch_gemm<4>(V, U, M, nt, Ci, Co, np, s)
-         : tile_env == 48 ? launch_gemm<1>(V, U, M, nt, Ci, Co, np, s)
-                          : launch_gemm<2>(V, U, M, nt, Ci, Co, np, s);
+    return launch_gemm<2>(V, U, M, nt, Ci, Co, np, s);
 }
 
 // tiles per chunk: V + M of one chunk <= DECNET_WINO_CHUNK_MB (1 GiB); equal chunks
@@ -1648,16 +1298,10 @@ size_t head_lds_bytes(int D, int H, int W) {
 
 // x != nullptr: the stack's input is a channels-last volume; x == nullptr: it is the cost volume of (left, right),
 // formed on chip by wino_head_transform
-struct StackTail {                                      // the 216 -> 1 unit + soft-argmax behind the stack (w == nullptr: none)
-    const float *w;
-    float scale, shift;
-    float *reg, *pred;
-};
-
 int conv_stack(const float *x, const float *left, const float *right, const float *const *u,
                const float *const *scale, const float *const *shift,
                int n_layers, int res_src, int res_dst, float *y, float *workspace, float *R, int B, int D, int H,
-               int W, int C, hipStream_t s, StackTail tail = StackTail{nullptr, 0.f, 0.f, nullptr, nullptr}) {
+               int W, int C, hipStream_t s) {
     constexpr int NP = 216;
     Tiling g{D, H, W, ceil_div(D, 4), ceil_div(H, 4), ceil_div(W, 4)};
     const int nt = B * g.Td * g.Th * g.Tw;
@@ -1687,38 +1331,13 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
     for (int i = 0; i < n_layers; ++i) {
         const bool last = i == n_layers - 1;
         // V of layer 0 comes from wino_input_transform (chunk major) unless the head kernel forms it, M of the last layer
-        // goes to wino_output_transform (chunk major) unless the tail kernel takes it; everything between is quad major
-        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0 || !x, !last || tail.w))) return rc;
-        if (last && tail.w) {
-            // (R is free again: res_dst < n_layers - 1)
-            const size_t tl = lds;
-            if (hipFuncSetAttribute((const void *)wino_tail_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl) != hipSuccess) {
-                (void)hipGetLastError();
-                return DECNET_ERR_UNSUPPORTED;
-            }
-            hipLaunchKernelGGL(wino_tail_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), tl, s, M,
-                               scale[i], shift[i], tail.w, R, g, C, nt, 1);
-            if ((rc = decnet_launch_status())) return rc;
-            const int PB = 256 / D, npix = B * H * W;
-            hipLaunchKernelGGL(cout1_reduce_softargmax, dim3((unsigned)ceil_div(npix, PB)), dim3(256), (size_t)PB * D * 4, s,
-                               R, tail.scale, tail.shift, tail.reg, tail.pred, B, D, H, W, (C + 3) / 4, PB);
-        } else if (last) {
+        // goes to wino_output_transform (chunk major); everything between is quad major
+        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0 || !x, !last))) return rc;
+        if (last) {
             const size_t n = (size_t)nt * pad16(C);
             hipLaunchKernelGGL((wino_output_transform<6, 6, 6, 1>), dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, s,
                                M, scale[i], shift[i], (const float *)nullptr, y, g, C, 1, 0, nt, bytes);
         } else {
-            static const int mid2 = [] { const char *e = getenv("DECNET_WINO_MID"); return e && atoi(e) == 2; }();
-            if (mid2) {                                 // half a quad per workgroup (measured alternative)
-                const int units = B * ((C + 3) / 4);
-                if (lds / 2 > 64 * 1024 &&
-                    hipFuncSetAttribute((const void *)wino_mid_transform2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return DECNET_ERR_UNSUPPORTED;
-                }
-                hipLaunchKernelGGL(wino_mid_transform2, dim3((unsigned)(16 * ceil_div(units, 8))), dim3(MID2_THREADS), lds / 2, s,
-                                   M, V, scale[i], shift[i], i == res_dst ? R : (const float *)nullptr,
-                                   i == res_src ? R : (float *)nullptr, g, C, nt, 1, units);
-            } else
             hipLaunchKernelGGL(wino_mid_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), lds, s, M, V,
                                scale[i], shift[i], i == res_dst ? R : (const float *)nullptr,
                                i == res_src ? R : (float *)nullptr, g, C, nt, 1);
@@ -1852,29 +1471,6 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
     const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
     return conv_stack(nullptr, left, right, u, scale, shift, n_layers, res_src, res_dst, y, workspace, workspace + w, B, D, H,
                       W, C, (hipStream_t)stream);
-}
-
-/* decnet_costvol_wino_stack_bn_act + the last unit of CostRegNetNoDown (Conv3d(C, 1, 3) + BN, submodule.py:648, 661;
- * w_last = its torch weight [1][C][3][3][3], BN folded to scale_last / shift_last) + disparity_regression
- * (submodule.py:766-777, samples 0 .. D-1): reg [B,D,H,W] (may be NULL) and pred [B,H,W].  The output of the last
- * C -> C layer is never written: its output transform forms the 27-tap sums of four channels at a time out of LDS. */
-int decnet_costvol_wino_stack_softargmax(const float *left, const float *right, const float *const *u,
-                                         const float *const *scale, const float *const *shift, int n_layers, int res_src,
-                                         int res_dst, const float *w_last, float scale_last, float shift_last, float *reg,
-                                         float *pred, float *workspace, int B, int C, int H, int W, int D, int variant,
-                                         void *stream) {
-    if (!left || !right || !u || !scale || !shift || !w_last || !pred || !workspace) return DECNET_ERR_NULL_POINTER;
-    if (B < 1 || D < 1 || H < 1 || W < 1 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
-    if (H < 2 || W < 2) return DECNET_ERR_UNSUPPORTED;   // the stretched warp of one row / column: per-layer path
-    for (int i = 0; i < n_layers; ++i)
-        if (!u[i] || !scale[i] || !shift[i]) return DECNET_ERR_NULL_POINTER;
-    if ((res_src < 0) != (res_dst < 0)) return DECNET_ERR_BAD_SHAPE;
-    if (res_src >= 0 && !(res_src < res_dst && res_dst < n_layers - 1)) return DECNET_ERR_UNSUPPORTED;
-    if (D > 256 || n_layers < 2 || !stack_ok(B, D, H, W, C, variant) || head_lds_bytes(D, H, W) > 160 * 1024)
-        return DECNET_ERR_UNSUPPORTED;
-    const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
-    return conv_stack(nullptr, left, right, u, scale, shift, n_layers, res_src, res_dst, nullptr, workspace, workspace + w, B,
-                      D, H, W, C, (hipStream_t)stream, StackTail{w_last, scale_last, shift_last, reg, pred});
 }
 
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale, const float *shift,

@@ -20,6 +20,7 @@
 // LDS: Os[Cq][OP] (OP == 4 mod 64: the contraction reads 4 consecutive pixels of one channel per
 //      lane with ds_read_b128, 16 channels x 4 quads conflict-free) | planes[NPL][OW].
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -627,6 +628,242 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? 4 : 2)) void spamat_bwd_sparse
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense rows, C <= 8, SpaMat (round 4): BOTH gradients from ONE pass over the cost / weight tiles.
+// The two band launches above form every 16 x 16 cost tile, its exponentials and weights twice (once per side) and
+// each reads both feature rows: stage 3, B = 4: 0.75 ms, 1.63 x the algorithmic bytes.  Here ONE WAVE OWNS ONE ROW and
+// walks its left tiles xt = 0, 1, ... in order.  For the tile pair (left tile xt, right tile xt - m):
+//   cost (2 fp32 MFMAs, rows = right pixels 4q + r, columns = left pixels j) -> weight w = e (d - out)      [once]
+//   gL[c][left]  += sum_right w R[c][right]     the weight registers are the MFMA operand as in spamat_bwd_mfma
+//   gR[c][right] += sum_left  w g/S L[c][left]  needs the TRANSPOSED tile as operand: four ds_write_b32 + one
+//                                               ds_read_b128 through a 1.25 KB per-wave scratch (in-order LDS, no barrier)
+// gL of a left tile is complete after its NT band tiles.  gR of a right tile collects from the NT left tiles xt .. xt +
+// NT - 1: the wave keeps a WINDOW of NT accumulator tiles gr[m] (right tile xt - m) in registers, stores gr[NT - 1]
+// when left tile xt is done and shifts the window by one -- no atomics, no cross-wave reduction, a fixed summation
+// order.  Nothing but a ring of the last NT right tiles (features [8][NT * 16], mask bias) lives in LDS; every input
+// byte is read once and every gradient byte written once.  Reference semantics: SM_kernel.cu:143-195 (ref), 300-355 (tar).
+constexpr int ROW_TSP = 20;                               // pitch of the transposition scratch (floats)
+constexpr int ROW_RING = 16;                              // ring of right tiles (>= NT, a power of two)
+constexpr int ROW_RP = ROW_RING * 16 + 4;                 // feature ring pitch == 4 (mod 64)
+constexpr int ROW_LDS_FLOATS = 8 * ROW_RP + ROW_RING * 16 + 2 * 16 * ROW_TSP;
+
+#ifndef DECNET_BWD_ROW_PIPE
+#define DECNET_BWD_ROW_PIPE 1
+#endif
+#ifndef DECNET_BWD_ROW_WPE
+#define DECNET_BWD_ROW_WPE 3          // waves per SIMD the register allocation of spamat_bwd_row is held to (measured: 1: 1.30,
+                                      // 2: 0.90, 3: 0.80 ms at stage 3, B = 4; the two band launches: 0.82)
+#endif
+template <int NT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DECNET_BWD_ROW_WPE, DECNET_BWD_ROW_WPE))) void spamat_bwd_row(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ out, const float *__restrict__ sum_sim,
+    const float *__restrict__ max_cost, const float *__restrict__ grad_out, float *__restrict__ grad_ref,
+    float *__restrict__ grad_tar, int C, int H, int W, int D, int marker) {
+    static_assert(NT <= ROW_RING, "band wider than the ring");
+    constexpr int RP = ROW_RP;
+    __shared__ __attribute__((aligned(16))) float smem[ROW_LDS_FLOATS];
+    float *RF = smem;                                    // [8][RP]: right features of the last 16 tiles (ring)
+    float *BZ = smem + 8 * RP;                           // [16 * 16]: 0 / -1e30 of the right mask (ring)
+    float *TS = BZ + ROW_RING * 16;                      // 2 x [16][ROW_TSP]: weight tiles, rows = right pixels
+    const int row = blockIdx.x, b = row / H, y = row - b * H;
+    const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
+    const size_t frow = ((size_t)b * C * H + y) * W;
+    if (marker && __float_as_int(grad_ref[frow]) != BWD_MARK) return;    // the sparse-row launches took this row
+    const float *lrow = ref + frow, *rrow = tar + frow;
+    float *glrow = grad_ref + frow, *grrow = grad_tar + frow;
+    const int lane = threadIdx.x, j = lane & 15, q = lane >> 4;
+    const int XT = (W + 15) >> 4;
+    const bool al4 = (W & 3) == 0 && ((((uintptr_t)ref) | ((uintptr_t)rmask) | ((uintptr_t)sum_sim) |
+                                       ((uintptr_t)grad_out) | ((uintptr_t)grad_ref)) & 15) == 0;
+    const int cj = j < C ? j : C - 1;                    // channel this lane supplies to / owns in the contractions
+    // right tiles left of the row (xt - m < 0) are walked like any other: zero features, mask off -> weights 0
+    for (int i = lane; i < 8 * RP; i += 64) RF[i] = 0.f;
+    for (int i = lane; i < ROW_RING * 16; i += 64) BZ[i] = NEG_BIG;
+
+    // "next tile" registers: everything left tile xt + 1 needs from HBM is requested while tile xt is computed
+    float nR[2], nL[2], nTm, nMax, nOut, nRm;
+    float4 nLq, nG4, nS4, nM4;
+    auto fetch = [&](int xt) {
+        const int x = xt * 16 + j, xq = xt * 16 + 4 * q;
+        const bool ok = xt < XT && x < W;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bool okc = ok && 4 * s + q < C;
+            nR[s] = okc ? rrow[(size_t)(4 * s + q) * plane + x] : 0.f;
+            nL[s] = okc ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
+        }
+        nTm = ok ? tmask[rowpix + x] : 0.f;
+        nRm = ok ? rmask[rowpix + x] : 0.f;
+        nMax = ok ? max_cost[rowpix + x] : 0.f;
+        nOut = ok ? out[rowpix + x] : 0.f;
+        const bool okq = xt < XT;
+        nLq = okq ? load4(lrow + (size_t)cj * plane, xq, W, al4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nG4 = okq ? load4(grad_out + rowpix, xq, W, al4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nS4 = okq ? load4(sum_sim + rowpix, xq, W, al4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        nM4 = okq ? load4(rmask + rowpix, xq, W, al4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+
+    f32x4 gr[NT];                                        // gr[m]: right tile xt - m; [r] = channel 4q + r, lane j = pixel
+#pragma unroll
+    for (int m = 0; m < NT; ++m) gr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // channel 4q + r of right tile t (complete) -> grad_tar, 0 where the right mask is off (SpaMat.py:43)
+    auto store_right = [&](int t, const f32x4 &g) {
+        const int x = t * 16 + j;
+        if (t < 0 || x >= W) return;
+        const bool on = BZ[(t & (ROW_RING - 1)) * 16 + j] == 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < C) grrow[(size_t)(4 * q + r) * plane + x] = on ? g[r] : 0.f;
+    };
+    const int tsw = j, tsr = j * ROW_TSP + 4 * q;       // scratch: write column / read row of this lane
+
+    for (int xt = 0; xt < XT; ++xt) {
+        const int x0 = xt * 16, s0 = xt & (ROW_RING - 1);
+        // commit tile xt: right features + mask bias into the ring (the slot held right tile xt - 16: dead), own operands
+        RF[q * RP + s0 * 16 + j] = nR[0];
+        RF[(q + 4) * RP + s0 * 16 + j] = nR[1];
+        if (q == 0) BZ[s0 * 16 + j] = nTm != 0.f ? 0.f : NEG_BIG;
+        const float bcur[2] = {nL[0], nL[1]};
+        // a masked-off (or out-of-row) left pixel takes part in no candidate: exp2(cost - 1e30) = 0
+        const float nm_own = nRm != 0.f ? -nMax * LOG2E : NEG_BIG;
+        const float out_own = nOut;
+        float gs[4];                                     // g / S of left pixels x0 + 4q + r, 0 where the left mask is off
+        {
+            const float g4[4] = {nG4.x, nG4.y, nG4.z, nG4.w}, s4[4] = {nS4.x, nS4.y, nS4.z, nS4.w},
+                        m4[4] = {nM4.x, nM4.y, nM4.z, nM4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gs[r] = (x0 + 4 * q + r < W && m4[r] != 0.f) ? g4[r] / s4[r] : 0.f;
+        }
+        // A operand of the right-gradient contraction: g/S L[c = j][x0 + 4q + r] (SM_kernel.cu:346), 0 for j >= C
+        const float lq[4] = {j < C ? nLq.x * gs[0] : 0.f, j < C ? nLq.y * gs[1] : 0.f, j < C ? nLq.z * gs[2] : 0.f,
+                             j < C ? nLq.w * gs[3] : 0.f};
+        fetch(xt + 1);
+        const float dj = (float)(j - 4 * q) - out_own;   // d - out = 16 m - r + dj
+        f32x4 gl = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // Software pipeline over the band (fully unrolled, one basic block): while the matrix pipe forms the cost tile of
+        // m + 1 the VALU turns the cost tile of m into weights; the transposed weights of m are read back one step later,
+        // behind the left-gradient MFMAs of m and the weights of m + 1 (two scratch tiles).
+        auto ring = [&](int m) { return ((xt - m) & (ROW_RING - 1)) * 16; };
+        auto cost = [&](int m) {
+            const int ob = ring(m);
+            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[q * RP + ob + j], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_16x16x4f32(RF[(q + 4) * RP + ob + j], bcur[1], c, 0, 0, 0);
+        };
+#if DECNET_BWD_ROW_PIPE
+        f32x4 cst = cost(0);
+        float4 tw_prev = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const int ob = ring(m);
+            f32x4 cst_next = cst;
+            if (m + 1 < NT) cst_next = cost(m + 1);
+            const float4 bz = *reinterpret_cast<const float4 *>(BZ + ob + 4 * q);
+            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+            const bool edge = m == 0 || 16 * m + 15 >= D;             // tiles that leave 0 <= d < D
+            f32x4 wt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float cc = cst[r] + bzv[r];
+                if (edge) {
+                    const int d = 16 * m + j - (4 * q + r);
+                    cc = (unsigned)d < (unsigned)D ? cc : NEG_BIG;
+                }
+                const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm_own));
+                wt[r] = e * ((float)(16 * m - r) + dj);               // SM_kernel.cu:191
+            }
+            float *ts = TS + (m & 1) * 16 * ROW_TSP;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ts[(4 * q + r) * ROW_TSP + tsw] = wt[r];
+            // left gradient: contraction over the tile's 16 right pixels (K step r <-> right pixel 4q + r)
+            const float4 ov = *reinterpret_cast<const float4 *>(RF + cj * RP + ob + 4 * q);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0], ov.x, gl, 0, 0, 0);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1], ov.y, gl, 0, 0, 0);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[2], ov.z, gl, 0, 0, 0);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[3], ov.w, gl, 0, 0, 0);
+            // right gradient of the PREVIOUS band tile: its transposed weights (rows = right pixels) are the B operand,
+            // K step r <-> left pixel 4q + r
+            if (m > 0) {
+                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[0], tw_prev.x, gr[m - 1], 0, 0, 0);
+                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[1], tw_prev.y, gr[m - 1], 0, 0, 0);
+                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[2], tw_prev.z, gr[m - 1], 0, 0, 0);
+                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[3], tw_prev.w, gr[m - 1], 0, 0, 0);
+            }
+            tw_prev = *reinterpret_cast<const float4 *>(ts + tsr);
+            cst = cst_next;
+        }
+        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[0], tw_prev.x, gr[NT - 1], 0, 0, 0);
+        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[1], tw_prev.y, gr[NT - 1], 0, 0, 0);
+        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[2], tw_prev.z, gr[NT - 1], 0, 0, 0);
+        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[3], tw_prev.w, gr[NT - 1], 0, 0, 0);
+#else
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            if (m > xt) continue;                        // right tile left of the row (uniform)
+            const int ob = ring(m);
+            const f32x4 cst = cost(m);
+            const float4 bz = *reinterpret_cast<const float4 *>(BZ + ob + 4 * q);
+            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+            const bool edge = m == 0 || 16 * m + 15 >= D;             // tiles that leave 0 <= d < D
+            f32x4 wt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float cc = cst[r] + bzv[r];
+                if (edge) {
+                    const int d = 16 * m + j - (4 * q + r);
+                    cc = (unsigned)d < (unsigned)D ? cc : NEG_BIG;
+                }
+                const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm_own));
+                wt[r] = e * ((float)(16 * m - r) + dj);               // SM_kernel.cu:191
+            }
+            float *ts = TS + (m & 1) * 16 * ROW_TSP;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ts[(4 * q + r) * ROW_TSP + tsw] = wt[r];
+            const float4 ov = *reinterpret_cast<const float4 *>(RF + cj * RP + ob + 4 * q);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0], ov.x, gl, 0, 0, 0);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1], ov.y, gl, 0, 0, 0);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[2], ov.z, gl, 0, 0, 0);
+            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[3], ov.w, gl, 0, 0, 0);
+            const float4 tw = *reinterpret_cast<const float4 *>(ts + tsr);
+            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[0], tw.x, gr[m], 0, 0, 0);
+            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[1], tw.y, gr[m], 0, 0, 0);
+            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[2], tw.z, gr[m], 0, 0, 0);
+            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[3], tw.w, gr[m], 0, 0, 0);
+        }
+#endif
+        // gl[r]: channel j, left pixel x0 + 4q + r: grad_ref = g * sum / S (SM_kernel.cu:193); masked-off pixels 0
+        if (j < C) {
+            float *gp = glrow + (size_t)j * plane + x0 + 4 * q;
+            if (al4 && x0 + 4 * q + 3 < W) {
+                *reinterpret_cast<float4 *>(gp) = make_float4(gl[0] * gs[0], gl[1] * gs[1], gl[2] * gs[2], gl[3] * gs[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (x0 + 4 * q + r < W) gp[r] = gl[r] * gs[r];
+            }
+        }
+        // right tile xt - (NT - 1) has seen all its left tiles: store, then slide the window
+        store_right(xt - (NT - 1), gr[NT - 1]);
+#pragma unroll
+        for (int m = NT - 1; m > 0; --m) gr[m] = gr[m - 1];
+        gr[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the last NT - 1 right tiles: after the final slide gr[m] holds right tile XT - m (m >= 1)
+#pragma unroll
+    for (int m = 1; m < NT; ++m) store_right(XT - m, gr[m]);
+}
+
+template <int NT>
+int launch_row(const float *ref, const float *tar, const float *rmask, const float *tmask, const float *out,
+               const float *sum_sim, const float *max_cost, const float *grad_out, float *grad_ref, float *grad_tar,
+               int B, int C, int H, int W, int D, int marker, hipStream_t stream) {
+    hipLaunchKernelGGL((spamat_bwd_row<NT>), dim3((unsigned)((size_t)B * H)), dim3(64), 0, stream, ref, tar, rmask, tmask,
+                       out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, C, H, W, D, marker);
+    return decnet_launch_status();
+}
+
 template <int NT, bool VAR, int KQ>
 int launch_both(const float *ref, const float *tar, const float *rmask, const float *tmask,
                 const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
@@ -678,6 +915,14 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
                 }
             }
         }
+    }
+    // dense rows at C <= 8 (SpaMat): both gradients from one pass, one wave per row (DECNET_SPAMAT_BWD=band: the two
+    // band launches below, which stay the path of SpaVar and of C > 8)
+    static const int band_only = [] { const char *e = getenv("DECNET_SPAMAT_BWD"); return e && !strcmp(e, "band"); }();
+    if constexpr (KQ == 2 && !VAR && NT <= 15) {
+        if (!band_only && W >= 16 * NT)
+            return launch_row<NT>(ref, tar, rmask, tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, B, C, H, W,
+                                  D, marker, stream);
     }
     int rc = launch_side<NT, VAR, KQ, 0>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
                                          grad_out, grad_ref, grad_disp, B, C, H, W, D, xt0, marker, stream);

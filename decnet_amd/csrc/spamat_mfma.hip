@@ -1227,27 +1227,6 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     }
 }
 
-// Rows the kernel above handed over with -2 (257 .. MID_CAP active pixels per side: densities 0.25 - 0.5 at stage 3): the
-// same body with MID_CAP slots and NT + 1 tiles per chunk on 256 threads -- 42 KB of LDS, three rows per CU in flight, where
-// the band kernel's own 512-thread workgroup (marker == 2, the default) holds two.  Opt-in (DECNET_SPAMAT_MID=1): the extra
-// launch and the halved threads per row cost more than the occupancy gives.  A row this body does not take either is
-// re-marked -1 for the band kernel.
-template <int NT, int MODE, int KQ, int PPT>
-__global__ __launch_bounds__(SP_THREADS, 4) void spamat_fwd_sparse_mid(
-    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
-    const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
-    float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int seg_w, int dense_pct, int mbits) {
-    const int row = blockIdx.x;
-    const size_t rowpix = (size_t)row * W;
-    if (sum_sim[rowpix] != -2.0f) return;
-    const int rc = sparse_row_body<NT, MODE, KQ, PPT, SP_THREADS, MID_CAP, NT + 1>(ref, tar, rmask, tmask, disparity, out,
-                                                                                  var_out, sum_sim, max_cost, C, H, W, D, row,
-                                                                                  dense_pct, mbits);
-    if (rc != 1)
-        for (int x = threadIdx.x * seg_w; x < W; x += SP_THREADS * seg_w) sum_sim[rowpix + x] = -1.0f;
-}
-
 template <int NT, int KQ>
 int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
               const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost,
@@ -1295,15 +1274,10 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     int marker = allow_compact && !sparse_off && (KQ == 2 || (KQ == 6 && sparse_c24)) && W <= 2048;
     // rows of 257-512 active pixels per side: the sparse-row algorithm inside the band kernel's workgroup (whole rows
     // per workgroup only; DECNET_SPAMAT_MID=0 switches it off)
-    // DECNET_SPAMAT_MID: 0 off | 2 (default) inside the band kernel's workgroup (512 threads, two rows per CU) |
-    // 1 their own 256-thread launch between the two (spamat_fwd_sparse_mid: three rows per CU, one more launch;
-    // measured 0.169 vs 0.152 ms at density 0.3, 0.316 vs 0.268 at 0.5)
-    static const int mid_mode = [] { const char *e = getenv("DECNET_SPAMAT_MID"); return e ? atoi(e) : 2; }();
-    const bool mid_off = mid_mode == 0;
-    const bool mid_own = mid_mode == 1 && KQ == 2 && marker && segs == 1 && W <= 1024 &&
-                         4 * sparse_row_words(2, 4, SP_THREADS, MID_CAP) <= DECNET_LDS_BYTES - 1024;
+    // DECNET_SPAMAT_MID=0 switches it off (a separate 256-thread launch for these rows was measured slower: tools/experiments)
+    static const bool mid_off = [] { const char *e = getenv("DECNET_SPAMAT_MID"); return e && atoi(e) == 0; }();
     size_t lds_launch = lds;
-    if (KQ == 2 && marker && segs == 1 && !mid_off && !mid_own) {
+    if (KQ == 2 && marker && segs == 1 && !mid_off) {
         const size_t need = 4 * sparse_row_words(KQ, 4, THREADS, MID_CAP);
         if (need <= budget2 + 8192) {
             marker = 2;
@@ -1336,25 +1310,6 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
 #undef LAUNCHS
         int rc = decnet_launch_status();
         if (rc) return rc;
-        if constexpr (KQ == 2) if (mid_own) {
-            const size_t mlds = 4 * sparse_row_words(2, 4, SP_THREADS, MID_CAP);
-#define LAUNCHM(M)                                                                                 \
-    do {                                                                                           \
-        if (mlds > 64 * 1024) {                                                                    \
-            hipError_t e = hipFuncSetAttribute((const void *)spamat_fwd_sparse_mid<NT, M, 2, 4>,   \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); \
-            if (e != hipSuccess) return (int)e;                                                    \
-        }                                                                                          \
-        hipLaunchKernelGGL((spamat_fwd_sparse_mid<NT, M, 2, 4>), dim3((unsigned)(B * H)), dim3(SP_THREADS), mlds, stream, \
-                           ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, XT * 16, \
-                           sparse_pct, mbits);                                                     \
-    } while (0)
-            if (mode == MODE_MAT) LAUNCHM(MODE_MAT);
-            else if (mode == MODE_VAR) LAUNCHM(MODE_VAR);
-            else LAUNCHM(MODE_FUSED);
-#undef LAUNCHM
-            if ((rc = decnet_launch_status())) return rc;
-        }
     }
 #define LAUNCH1(M, DD)                                                                             \
     do {                                                                                           \

@@ -54,12 +54,6 @@ int decnet_stage0_forward(const float *left, const float *right, const decnet_st
     float *t_last = last > act ? ws + wino : a;
 
     int rc = DECNET_ERR_UNSUPPORTED;
-    // (the last unit fused behind the stack is correct but slower than the three kernels it replaces: opt-in)
-    static const int tail_on = [] { const char *e = getenv("DECNET_WINO_TAIL"); return e && atoi(e) == 1; }();
-    if (stack && tail_on)   // the whole branch: cost volume, seven layers, last unit, soft-argmax; only transformed tiles in HBM
-        rc = decnet_costvol_wino_stack_softargmax(left, right, p->w, p->scale, p->shift, 7, 1, 4, p->w_last, p->scale_last,
-                                                  p->shift_last, reg, pred, ws, B, C, H, W, D, variant, stream);
-    if (rc != DECNET_ERR_UNSUPPORTED) return rc;
     if (stack)      // cost volume + all seven layers, neither the volume nor the activations between the layers in HBM
         rc = decnet_costvol_wino_stack_bn_act(left, right, p->w, p->scale, p->shift, 7, 1, 4, c, ws, B, C, H, W, D, variant,
                                               stream);

@@ -174,15 +174,6 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
                                      const float *const *scale, const float *const *shift, int n_layers, int res_src,
                                      int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
                                      int variant, void *stream);
-/* ... and with the last unit of CostRegNetNoDown (Conv3d(C, 1, 3) + BN, submodule.py:648, 661: w_last = its torch weight
- * [1][C][3][3][3], BN folded to scale_last / shift_last) and disparity_regression (submodule.py:766-777, samples 0..D-1)
- * behind it: reg [B,D,H,W] (may be NULL), pred [B,H,W].  The last C -> C layer's output is never written either. */
-int decnet_costvol_wino_stack_softargmax(const float *left, const float *right, const float *const *u,
-                                         const float *const *scale, const float *const *shift, int n_layers, int res_src,
-                                         int res_dst, const float *w_last, float scale_last, float shift_last, float *reg,
-                                         float *pred, float *workspace, int B, int C, int H, int W, int D, int variant,
-                                         void *stream);
-
 /* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
  * over disp_samples = arange(D) (submodule.py:766-777):
  *   reg[b,d,y,x]  = conv(x)[b,d,y,x] * scale + shift        (optional output, may be NULL)
@@ -255,6 +246,9 @@ int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *sca
  * (host arrays of device pointers / channel counts; weights packed for Cin = sum of cins): the
  * torch.cat in front of the Deconv2dBlock / Refinement / SoftAttention convolutions
  * (submodule.py:176, 755, SparseDenseNetRefinementMask.py:195-199) is never materialised. */
+int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, const float *w_packed,
+                             const float *scale, const float *shift, float *y, int B, int Cout, int H,
+                             int W, int k, int dilation, int relu, void *stream);
 /* decnet_conv2d_cat_bn_act for a layer with ONE output channel, with the elementwise tail of its caller fused
  * (ea, eb: [B,H,W] planes; y [B,1,H,W]):
  *   epilogue 1  SoftAttention's last layer + the fusion of the stage loop (submodule.py:593-604,
@@ -263,9 +257,6 @@ int decnet_conv2d_bn_act(const float *x, const float *w_packed, const float *sca
 int decnet_conv2d_cat_epilogue(const float *const *xs, const int *cins, int nseg, const float *w_packed,
                                const float *scale, const float *shift, float *y, int B, int H, int W, int k,
                                int dilation, int relu, int epilogue, const float *ea, const float *eb, void *stream);
-int decnet_conv2d_cat_bn_act(const float *const *xs, const int *cins, int nseg, const float *w_packed,
-                             const float *scale, const float *shift, float *y, int B, int Cout, int H,
-                             int W, int k, int dilation, int relu, void *stream);
 /* The many-channel stride-1 Conv2dUnit layers (FeatureExtraction conv1-conv3_2 and the Deconv2dBlock convolutions
  * submodule.py:245-343, 162-178; DynamicUpsampling.weight_learning :566-577; Refinement :690-717) on the bf16
  * matrix cores at fp32 accuracy (each fp32 operand split into three bf16 terms, six partial products): k = 1 or 3,
@@ -308,13 +299,13 @@ int decnet_detail_mask(const float *cur3, const float *pre3, const float *w3x3, 
                        void *stream);
 /* Head of DynamicUpsampling.forward (submodule.py:578-580): out = cat(disp, unfold(fea, 3, stride 3)):
  * fea [B,C,3h,3w], disp [B,h,w] -> out [B,9C+1,h,w], out[b,0] = disp, out[b,1+9c+3i+j,y,x] = fea[b,c,3y+i,3x+j]. */
+int decnet_unfold3_cat(const float *fea, const float *disp, float *out, int B, int C, int h, int w,
+                       void *stream);
 /* Space-to-depth in front of the stride-3 convolutions of FeatExtNetChannelPlus (Conv2d k 3, stride 3, padding 1,
  * submodule.py:270-300): x [B,C,H,W] -> out [B,9C,Ho,Wo], Ho = (H-1)/3+1, Wo = (W-1)/3+1,
  * out[b,c*9+ky*3+kx,yo,xo] = x[b,c,3yo-1+ky,3xo-1+kx] (0 outside); the convolution is then the 1 x 1 convolution with the
  * weight [Cout,Cin,3,3] read as [Cout,9 Cin] (decnet_conv2d_mfma_cat_bn_act, k = 1). */
 int decnet_s2d3_pad1(const float *x, float *out, int B, int C, int H, int W, void *stream);
-int decnet_unfold3_cat(const float *fea, const float *disp, float *out, int B, int C, int h, int w,
-                       void *stream);
 /* y[b,c,:,:] = act(y[b,c,:,:] + shift[c]) in place, y [B,C,H,W]: the folded-BatchNorm bias and the ReLU
  * behind a library convolution, one pass.  B*C <= 65535. */
 int decnet_bias_act_inplace(float *y, const float *shift, int B, int C, int H, int W, int relu,
@@ -347,68 +338,6 @@ int decnet_tap_gemm(const float *V, const float *u, float *M, int P, int Ci, int
 int decnet_tapconv_gather(const float *M, const float *scale, const float *shift, float *y, int B,
                           int Co, int H, int W, int nbranch, const int *tap0, const int *k,
                           const int *dil, int relu, void *stream);
-
-/* ---------------------------------------------------------------------------------------
- * Fused chains of few-channel convolutions (csrc/chain2d.hip): source -> up to three Conv2dUnit layers with
- * <= 8 output channels each (3x3 with dilation d, padding d, stride 1; or 1x1) -> sink, ONE launch, intermediate
- * rows in LDS.  Covers, in eval mode (BatchNorm folded to scale / shift):
- *   FeatExtNetChannelPlus.conv0                      submodule.py:263-266   image -> 3x3 -> 3x3
- *   Deconv2dBlock of the finest level                submodule.py:162-178   cat(deconv(x), skip) -> 3x3 -> 3x3
- *   GenerateSparseMask (+ sigmoid > thold)           submodule.py:347-372, SparseDenseNetRefinementMask.py:158-170
- *   SoftAttention (+ the dense / sparse fusion)      submodule.py:593-604, SparseDenseNetRefinementMask.py:195-202
- *   Refinement: warp + first layers                  submodule.py:690-745
- * Source parts are concatenated along the channel axis in the order given:
- *   DECNET_PART_PLAIN   p [B,c,H,W] (p2: the tensor that holds samples b >= bsplit as its samples b - bsplit, or NULL)
- *   DECNET_PART_DECONV  8 channels = act(scale * ConvTranspose2d(k 3, stride 3)(p [B,cp,H/3,W/3]) + shift); aux = the
- *                       weights packed by decnet_conv2d_pack_weight(..., transposed = 1): [cp][3][3][8]
- *   DECNET_PART_WARP    c <= 8 channels = Refinement's disparity warp of p [B,c,H,W] by aux [B,H,W]
- *                       (= decnet_warp_disparity); generated parts must start at a multiple of 8 channels
- * Layer l: weights packed by decnet_chain2d_pack_weight into w_packed at the offset
- *   sum_{i<l} decnet_chain2d_packed_bytes(cin_i, k_i);  y = act(scale * conv(x) + shift);  epilogue
- *   DECNET_EPI_SUBSQ: y = (aux[b,co] - y)^2 (aux [B,aux_channels,H,W]).
- * Sinks: STORE out [B,cout,H,W]; BLEND (cout 1): out [B,H,W] = a (1 - s) + s b, s = sigmoid(y), a = sink_a, b = sink_b
- *   [B,H,W]; ADD (cout 1): out = sink_a + y; MASK (cout 3): z = mask_scale * sum_c mask_w[c] y_c + mask_shift,
- *   out [B,H,W] = sigmoid(z) > thold ? 1 : 0 and, if bits != NULL, the bit-packed copy [B,H,ceil(W/64)] words.
- * DECNET_ERR_UNSUPPORTED: more than 8 output channels, more than 96 source channels, H or W not a multiple of 3
- * with a DECONV part, LDS budget.                                                                               */
-#define DECNET_CHAIN_MAX_LAYERS 3
-#define DECNET_CHAIN_MAX_PARTS 6
-#define DECNET_PART_PLAIN 0
-#define DECNET_PART_DECONV 1
-#define DECNET_PART_WARP 2
-#define DECNET_EPI_AFFINE 0
-#define DECNET_EPI_SUBSQ 1
-#define DECNET_SINK_STORE 0
-#define DECNET_SINK_BLEND 1
-#define DECNET_SINK_ADD 2
-#define DECNET_SINK_MASK 3
-typedef struct decnet_chain_part {
-    const float *p, *p2, *aux, *scale, *shift;
-    int c, kind, cp, relu;
-} decnet_chain_part;
-typedef struct decnet_chain_layer {
-    const float *scale, *shift;      /* HOST arrays [cout] */
-    const float *aux;                /* device, DECNET_EPI_SUBSQ */
-    int cin, cout, k, dilation, relu, epilogue, aux_channels;
-} decnet_chain_layer;
-typedef struct decnet_chain_desc {
-    decnet_chain_part parts[DECNET_CHAIN_MAX_PARTS];
-    decnet_chain_layer layers[DECNET_CHAIN_MAX_LAYERS];
-    const void *w_packed;
-    float *out;
-    unsigned long long *bits;
-    const float *sink_a, *sink_b;
-    float mask_w[3], mask_scale, mask_shift, thold;
-    int n_parts, n_layers, bsplit, B, H, W, sink;
-    int force_tw, force_rows;        /* 0: planned; > 0: pin the strip width / rows per workgroup (tests, tuning) */
-    int debug;                       /* 0.  Timing experiments only (results are wrong): 1 no MFMAs, 2 no source loads, 4 no
-                                        source commit, 8 no output stores, 16 no level stores, 256 print the plan */
-} decnet_chain_desc;
-size_t decnet_chain2d_packed_bytes(int Cin, int k);
-/* w [Cout,Cin,k,k] (torch Conv2d), sign NULL or [Cin] device (+-1: a negated input channel folded into the weights) */
-int decnet_chain2d_pack_weight(const float *w, const float *sign, void *w_packed, int Cin, int Cout, int k,
-                               void *stream);
-int decnet_chain2d_forward(const decnet_chain_desc *desc, void *stream);
 
 /* Layout helpers between the reference's [B,C,D,H,W] and the internal [B,D,H,W,C]. */
 int decnet_ncdhw_to_ndhwc(const float *src, float *dst, int B, int C, int D, int H, int W,

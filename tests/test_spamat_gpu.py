@@ -411,11 +411,11 @@ def test_mask_kernel_bits_feed_the_bit_mask_call(dev):
     assert 0.2 < float(m.mean()) < 0.8
 
 
-@pytest.mark.parametrize("env", [{"DECNET_SPAMAT_MID": "1"}, {"DECNET_SPAMAT_MID": "0"}, {"DECNET_SPAMAT_SPARSE_PCT": "35"}])
-def test_mid_density_switches(env):
-    """Rows of 257 - 640 active pixels per side under the other settings of their path (own 256-thread launch; off: the band
-    kernel's compact / dense paths; the round-2 threshold): the mixed-density and randomized cases in a child process each
-    (the switches are read once per process)."""
+@pytest.mark.parametrize("env", [{"DECNET_SPAMAT_MID": "0"}])
+def test_mid_density_rows_on_the_band_kernels_own_paths(env):
+    """Rows of 257 - 640 active pixels per side on the band kernel's compact / dense paths -- what they take wherever the
+    640-slot body does not fit LDS (wide rows, several segments) -- forced at the shipped shapes: the mixed-density and
+    randomized cases in a child process (the switch is read once per process)."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",

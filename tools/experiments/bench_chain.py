@@ -6,9 +6,10 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+_H = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(_H, "..", ".."), _H]
 import bench  # noqa: E402
-from decnet_amd import chain  # noqa: E402
+import chain  # noqa: E402
 from decnet_amd.model import Unit  # noqa: E402
 
 CASES = [

@@ -1,11 +1,41 @@
-"""Host side of csrc/chain2d.hip: chains of few-channel Conv2dUnit layers as one launch (include/decnet_hip.h,
-``decnet_chain2d_forward``).  Builds the C descriptor from ``model.Unit`` modules (eval mode, BatchNorm folded) and
+"""EXPERIMENT, not part of the product (tools/experiments/README.md).
+Host side of tools/experiments/chain2d.hip: chains of few-channel Conv2dUnit layers as one launch
+(tools/experiments/decnet_chain2d.h, ``decnet_chain2d_forward``; built by tools/experiments/build.sh).  Builds the C descriptor from ``model.Unit`` modules (eval mode, BatchNorm folded) and
 caches the packed weights per weight version.  No CPU fallback."""
 import ctypes
 
 import torch
 
-from . import _lib
+import os
+
+from decnet_amd import _lib as _prod
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _ChainLib:
+    """ctypes handle of tools/experiments/libdecnet_chain2d.so with decnet_amd._lib's error convention."""
+    _h = None
+    check = staticmethod(_prod.check)
+    DecnetHipError = _prod.DecnetHipError
+    UNSUPPORTED = _prod.UNSUPPORTED
+
+    @classmethod
+    def lib(cls):
+        if cls._h is None:
+            path = os.path.join(_HERE, "libdecnet_chain2d.so")
+            if not os.path.exists(path):
+                raise _prod.DecnetHipError("%s not built: run tools/experiments/build.sh" % path)
+            h = ctypes.CDLL(path)
+            h.decnet_chain2d_packed_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+            h.decnet_chain2d_packed_bytes.restype = ctypes.c_size_t
+            h.decnet_chain2d_pack_weight.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+            h.decnet_chain2d_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            cls._h = h
+        return cls._h
+
+
+_lib = _ChainLib
 
 _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 MAX_LAYERS, MAX_PARTS = 3, 6

@@ -1,4 +1,4 @@
-// decnet_amd/csrc/chain2d.hip -- chains of few-channel 3x3 convolutions as ONE kernel.
+// tools/experiments/chain2d.hip (EXPERIMENT, not in libdecnet_hip.so; was decnet_amd/csrc/chain2d.hip) -- chains of few-channel 3x3 convolutions as ONE kernel.
 //
 // The full-resolution parts of the trunk are chains of Conv2dUnit layers with <= 8 output channels
 // (modules/submodule.py): FeatExtNet conv0 (:263-266), Deconv2dBlock of the finest level (:162-178),
@@ -26,6 +26,7 @@
 // (static split by MFMA count), all layers run skewed in the same step (layer j computes row s + off_j, off_j =
 // off_{j+1} + d_{j+1} + 1), one barrier per row step.
 #include "common.h"
+#include "decnet_chain2d.h"
 #include <stdio.h>
 
 typedef float f32x4_h __attribute__((ext_vector_type(4)));
@@ -629,7 +630,7 @@ int decnet_chain2d_pack_weight(const float *w, const float *sign, void *w_packed
     return decnet_launch_status();
 }
 
-// Plans the strips / rows / waves of one chain and launches it.  See include/decnet_hip.h for the descriptor.
+// Plans the strips / rows / waves of one chain and launches it.  See decnet_chain2d.h for the descriptor.
 int decnet_chain2d_forward(const decnet_chain_desc *d, void *stream) {
     if (!d || !d->out) return DECNET_ERR_NULL_POINTER;
     const int NL = d->n_layers, B = d->B, H = d->H, W = d->W;

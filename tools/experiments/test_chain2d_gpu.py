@@ -1,8 +1,14 @@
-"""Parity of the fused conv-chain kernel (csrc/chain2d.hip, decnet_chain2d_forward) with the torch CPU ops the
+"""Parity of the fused conv-chain kernel (tools/experiments/chain2d.hip, decnet_chain2d_forward; EXPERIMENT, run by hand after tools/experiments/build.sh) with the torch CPU ops the
 reference calls layer by layer (modules/submodule.py:15-45: conv2d -> batch_norm(eval) -> relu), in float64.  -m gpu.
 Tolerance: 1e-5 * max|y| per chain (bf16x3 products on the matrix cores = every product above 2^-24, fp32 sums)."""
+import os
+import sys
+
 import pytest
 import torch
+
+_H = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(_H, "..", ".."), _H]
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +65,7 @@ CHAINS = [
 @pytest.mark.parametrize("idx", range(len(CHAINS)))
 @pytest.mark.parametrize("force", [(0, 0), (16, 5), (48, 11)])
 def test_chain_vs_torch_cpu(dev, idx, force):
-    from decnet_amd import chain
+    import chain
     specs, split, (B, H, W) = CHAINS[idx]
     units = [_unit(*s, seed=100 * idx + i) for i, s in enumerate(specs)]
     g = torch.Generator().manual_seed(idx)
