@@ -17,8 +17,13 @@ ori_h, ori_w, name, n_disp`` with the images padded on the top/left to multiples
 
 Without stored masks the three per-view detail masks come from decnet_amd.masks.detail_detection (the
 reference bakes the same function's output into the pickles); with ``use_detail`` the network ignores them
-(SparseDenseNetRefinementMask.py:148-170) and ones are returned.  Training-time augmentation
-(random crops, add_paralex_noise) is not part of the inference hot path and is not reproduced.
+(SparseDenseNetRefinementMask.py:148-170) and ones are returned.
+
+Training mode (``NpyPairs(..., is_training=True, img_size=...)``, round 4): the reference's training branch --
+random crop (masks cropped with it), reflected-light stripes, KITTI's occlusion rectangle / object mask /
+RandomPhotometric -- in decnet_amd.augment, drawn from numpy's global generator in the reference's order; the sample
+is then the 10-tuple of SceneflowMask.py:195-196.  Middlebury's training branch (its own crop policy,
+MiddleburyMask.py:152-237) is not reproduced.
 """
 import math
 import os
@@ -91,8 +96,11 @@ class _Base(data.Dataset):
 
 
 class NpyPairs(_Base):
-    def __init__(self, root, split="test", **kw):
+    """policy: which dataset's training branch ``is_training`` follows ('sceneflow' | 'kitti' | 'drivingstereo')."""
+
+    def __init__(self, root, split="test", is_training=False, img_size=(540, 960), policy="sceneflow", **kw):
         super().__init__(**kw)
+        self.is_training, self.img_size, self.policy = is_training, tuple(img_size), policy
         p = os.path.join(root, split)
         if os.path.isfile(p):
             self.paths = sorted(str(s) for s in np.load(p))
@@ -115,8 +123,29 @@ class NpyPairs(_Base):
             with open(mpath, "rb") as f:
                 m = pickle.load(f)
             lm, rm = m[0:3], m[3:6]
+        if self.is_training:
+            return self._train_item(arr, None if lm is None else list(lm) + list(rm))
         # no per-sample disparity range in this layout: n_disp <= 0 tells eval to keep --max_disp
         return self._item(arr[..., 0:3], arr[..., 3:6], arr[..., 6], name, -1, lm, rm)
+
+    def _train_item(self, arr, stored):
+        """SceneflowMask.py:115-196 / KITTI15Mask.py:105-211 with is_training: pad, crop, augment, normalise; the
+        10-tuple left, right, disparity, image, left_mask1..3, right_mask1..3."""
+        from . import augment
+        data = pad_top_left(arr.astype(np.float32))
+        left, right, disp, image, stored = augment.prepare_training_sample(data, stored, self.policy, self.img_size)
+        lm = _masks(left, None if stored is None else stored[0:3], self.use_detail)
+        rm = _masks(right, None if stored is None else stored[3:6], self.use_detail)
+        jitter = augment.photometric(self.policy)
+        views = []
+        for v in (left, right):                                             # left first, then right (KITTI15Mask.py:240-241)
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32).transpose(2, 0, 1)))
+            if jitter is not None:
+                t = jitter(t)
+            views.append(((t - torch.from_numpy(MEAN)[:, None, None]) / torch.from_numpy(STD)[:, None, None]).float())
+        img = torch.from_numpy(np.ascontiguousarray(np.asarray(image, np.float32).transpose(2, 0, 1)))
+        gt = torch.from_numpy(np.ascontiguousarray(disp, dtype=np.float32))
+        return (views[0], views[1], gt, img, lm[0], lm[1], lm[2], rm[0], rm[1], rm[2])
 
 
 class MiddleburyPickles(_Base):
@@ -192,3 +221,8 @@ def get_loader(name):
     pickled-dict layout; + 'pairs' (demo.py's directories)."""
     return {"kitti15mask": NpyPairs, "sceneflowmask": NpyPairs, "drivingstereomask": NpyPairs,
             "middleburymask": MiddleburyPickles, "pairs": PairDirectory}[name.lower()]
+
+
+def training_policy(name):
+    """Which training branch a dataset name selects in NpyPairs(is_training=True, policy=...)."""
+    return {"kitti15mask": "kitti", "sceneflowmask": "sceneflow", "drivingstereomask": "drivingstereo"}[name.lower()]
