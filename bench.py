@@ -117,6 +117,7 @@ class HotPath:
         self.gbuf, self.pending, self.k = [None, None], [None, None], 0
         self.side = None
         self.ev = None
+        self.gstream = None                             # the stream the all-gather is issued from (round 4)
         self.overlap = True                             # --no-overlap: everything in order on one stream
 
     def drain(self):
@@ -161,19 +162,38 @@ class HotPath:
                 if events is not None and s == 3:
                     events["s3_end"].record()
 
+        gather_own = self.coll and os.environ.get("DECNET_GATHER_STREAM", "1") != "0"
+        ev3 = None
         if overlap:
             with torch.cuda.stream(self.side):
                 sparse_stages()
+                if gather_own:
+                    ev3 = torch.cuda.Event()
+                    ev3.record()                                     # stage-3 disparity of this step is complete
             pred0 = stage0()
-            cur.wait_stream(self.side)
+            if not gather_own:
+                cur.wait_stream(self.side)
         else:
             pred0 = stage0()
             sparse_stages()
         disp = self.outs3[self.k & 1 if self.coll else 0][0]
         if self.coll:            # one RCCL all-gather of the per-rank disparity maps, not waited for here
             par = self.k & 1
-            disp, self.pending[par] = self.dist.gather_disparity(disp, n_pairs=self.world * self.B,
-                                                                 out=self.gbuf[par], async_op=True)
+            if gather_own:
+                # issued from its own stream, ordered behind the stage-3 kernels by ONE event: RCCL's stream then follows
+                # the side stream only, and the main stream (stage 0 of this and the next step) is never joined to it
+                if self.gstream is None:
+                    self.gstream = torch.cuda.Stream()
+                if ev3 is None:
+                    ev3 = torch.cuda.Event()
+                    ev3.record()
+                self.gstream.wait_event(ev3)
+                with torch.cuda.stream(self.gstream):
+                    disp, self.pending[par] = self.dist.gather_disparity(disp, n_pairs=self.world * self.B,
+                                                                         out=self.gbuf[par], async_op=True)
+            else:
+                disp, self.pending[par] = self.dist.gather_disparity(disp, n_pairs=self.world * self.B,
+                                                                     out=self.gbuf[par], async_op=True)
             self.gbuf[par] = disp
             self.k += 1
         return pred0, disp

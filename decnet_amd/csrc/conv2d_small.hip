@@ -12,6 +12,9 @@
 //   deconv2d_k3s3<CO>      ConvTranspose2d k = 3, stride 3, padding 0: every output pixel has exactly
 //                          one tap, in[y/3][x/3] * w[ci][co][y%3][x%3]              (Deconv2dUnit)
 //   conv2d_k3s3<CO>        k = 3, stride 3, padding 1 (the down-sampling convs of FeatExtNet)
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 typedef int i32x4_c __attribute__((ext_vector_type(4)));
@@ -122,6 +125,129 @@ __global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__rest
                     if (x0 + e < W) yp[e] = o[e];
             }
         }
+}
+
+#ifndef DECNET_F32M_CH
+#define DECNET_F32M_CH 1            // input channels whose taps are in flight together in conv2d_f32m
+#endif
+// ---- the same layers on the fp32 matrix pipe (round 4) ------------------------------------------------------------
+// conv2d_small above runs its multiply-adds as v_pk_fma_f32 with an SGPR weight pair: 60 - 70 TFLOP/s whatever the
+// occupancy (8 -> 8 is HBM-shaped at that rate, but 12 / 16 / 17 -> 8 -- the concatenated inputs of Deconv2dBlock,
+// SoftAttention and Refinement -- take 1.5 - 2 x their HBM time).  v_mfma_f32_4x4x1_16B_f32 does 16 independent
+// 4 x 4 outer products per wave-instruction (block b = lane / 4: D[i][j] += A[4b + i] * B[4b + j]) at the full fp32
+// matrix rate (tools/ubench/mfma4x4: 125 TFLOP/s from two accumulator chains) and, unlike the 16 x 16 / 32 x 32
+// shapes, wastes nothing at 4, 8, 12 or 24 output channels:
+//     A = the input value of the lane's OWN pixel (lane <-> pixel x0 + lane, one row of 64 pixels per wave),
+//     B = the weight of output channel 4 cog + (lane & 3) for this (input channel, tap), read from LDS,
+//     D: lane 4b + j, register i = pixel x0 + 4b + i, channel 4 cog + j  -> one 16-byte store per accumulator.
+// A wave owns 64 pixels x R output rows spaced by the dilation (so that the R + 2 input rows serve all of them), the
+// taps x - d, x, x + d are three bounds-checked dword loads per input row (out of range = 0, no halo logic), the
+// result is the same k-ordered fp32 fma chain per output as before (input channels outermost, then ky, kx).
+template <int COQ, int K, int R>
+__global__ __launch_bounds__(256) void conv2d_f32m(Segs in, const float *__restrict__ w,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   float *__restrict__ y, int Cout, int H, int W, int dil, int relu,
+                                                   int ntasks, int tasks_per_img, int cin) {
+    constexpr int CO = 4 * COQ, KK = K * K, NR = K == 1 ? R : R + 2;
+    extern __shared__ float wl[];                        // [cin][KK][4 (j)][COQ]: a lane's COQ weights are adjacent
+    for (int i = threadIdx.x; i < cin * KK * CO; i += 256) {
+        const int e = i % CO, rest = i / CO, j = e / COQ, cog = e - j * COQ;
+        wl[i] = w[rest * CO + 4 * cog + j];
+    }
+    __syncthreads();
+    int bx, task;
+    if (!decnet_xcd_rows((W + 255) >> 8, ntasks, bx, task)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = (bx * 4 + wave) * 64;
+    if (x0 >= W) return;
+    const int x = x0 + lane;
+    const int b = task / tasks_per_img, t = task - b * tasks_per_img;
+    const int yb = (t / dil) * R * dil + (t % dil);      // output rows yb + r * dil
+    const size_t plane = (size_t)H * W;
+    size_t roff[NR];
+    int rbytes[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {                    // wave-uniform
+        const int yi = yb + (rr - K / 2) * dil;
+        const bool ok = (unsigned)yi < (unsigned)H;
+        roff[rr] = ok ? (size_t)yi * W : 0;
+        rbytes[rr] = ok ? W * 4 : 0;                     // a row outside the image reads as zeros
+    }
+    typedef float f32x4_m __attribute__((ext_vector_type(4)));
+    f32x4_m acc[R][COQ];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < COQ; ++c) acc[r][c] = f32x4_m{0.f, 0.f, 0.f, 0.f};
+    const float *wlane = wl + (lane & 3) * COQ;
+    // CHB channels per step: all their taps are requested before the first MFMA (no loop-carried tap registers)
+    constexpr int CHB = DECNET_F32M_CH;
+    int sg = 0, cs = 0;
+    auto plane_ptr = [&]() { return in.p[sg] + ((size_t)b * in.c[sg] + cs) * plane; };
+    auto advance = [&]() { if (++cs == in.c[sg]) { cs = 0; ++sg; } };
+    for (int ci = 0; ci < cin; ci += CHB) {
+        float v[CHB][NR][K];
+        const float *base = plane_ptr();
+#pragma unroll
+        for (int u = 0; u < CHB; ++u) {
+            const bool live = ci + u < cin;
+            const float *xp = live ? plane_ptr() : base;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const __amdgpu_buffer_rsrc_t rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc((void *)(xp + roff[rr]), 0, live ? rbytes[rr] : 0, 0x00020000);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)          // x - d < 0: a huge unsigned offset; x + d >= W: past the row
+                    v[u][rr][kx] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (x + (kx - K / 2) * dil) * 4, 0, 0));
+            }
+            if (live) advance();
+        }
+#pragma unroll
+        for (int u = 0; u < CHB; ++u) {
+            if (ci + u >= cin) break;
+            const float *wc = wlane + (ci + u) * KK * CO;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    float wv[COQ];
+#pragma unroll
+                    for (int c = 0; c < COQ; ++c) wv[c] = wc[(ky * K + kx) * CO + c];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int c = 0; c < COQ; ++c)
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(v[u][r + ky][kx], wv[c], acc[r][c], 0, 0, 0);
+                }
+        }
+    }
+    const int j = lane & 3, xq = x0 + (lane & ~3);       // this lane's four pixels xq .. xq + 3
+    const bool vec = (W & 3) == 0 && ((uintptr_t)y & 15) == 0;
+#pragma unroll
+    for (int c = 0; c < COQ; ++c) {
+        const int co = 4 * c + j;
+        if (co >= Cout) continue;
+        const float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = yb + r * dil;
+            if (row >= H) break;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = fmaf(acc[r][c][e], sc, sh);
+                if (relu) o[e] = fmaxf(o[e], 0.f);
+            }
+            float *yp = y + ((size_t)b * Cout + co) * plane + (size_t)row * W + xq;
+            if (vec && xq + 3 < W) {
+                *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (xq + e < W) yp[e] = o[e];
+            }
+        }
+    }
 }
 
 // weights packed [Cin][3][3][CO] (decnet_conv2d_pack_weight, transposed = 1); output (3H) x (3W).
@@ -392,6 +518,31 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
     if ((double)B * (cin > Cout ? cin : Cout) * H * W >= 9.0e18) return DECNET_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     if (epi && (Cout != 1 || !ea || (epi == 1 && !eb) || epi < 0 || epi > 2)) return DECNET_ERR_UNSUPPORTED;
+    // 3 x 3 layers with <= 4 outputs or more than 8 inputs: the fp32 matrix-pipe kernel.  Measured against the packed-FMA
+    // kernel at [8,*,540,972] (tools/bench_conv2d_shapes.sh): 16 -> 8 0.149 vs 0.160 ms, 17 -> 8 dilation 3 0.167 vs
+    // 0.175, 12 -> 8 0.121 vs 0.129, 8 -> 4 0.045 vs 0.054, 8 -> 3 0.043 vs 0.053; the 8 -> 8 layers (HBM-shaped either
+    // way: 0.077 vs 0.072), 3 -> 8 and the 1 x 1 layers stay on the packed-FMA kernel with its eight waves per SIMD.
+    // DECNET_CONV2D_SMALL=valu | mfma forces one of them.
+    static const int force = [] { const char *e = getenv("DECNET_CONV2D_SMALL"); return !e ? 0 : !strcmp(e, "valu") ? 1 : !strcmp(e, "mfma") ? 2 : 0; }();
+    const int cop = co_pad(Cout);
+    const bool want_mfma = force == 2 || (force == 0 && k == 3 && (cop <= 4 || cin > 8));
+    if (want_mfma && Cout > 1 && (size_t)cin * k * k * cop * 4 <= 64 * 1024 && H <= 65535) {
+        const size_t lds = (size_t)cin * k * k * cop * 4;
+        const int R = cop <= 8 ? 4 : 2;
+        const int tasks_per_img = ceil_div(H, R * dilation) * dilation;
+        const long ntasks = (long)tasks_per_img * B;
+        if ((double)ntasks * ceil_div(W, 256) < 2.0e9) {
+            const dim3 grid(decnet_xcd_grid(ceil_div(W, 256), ntasks));
+#define GOM(Q, KK_, R_)                                                                                             \
+    hipLaunchKernelGGL((conv2d_f32m<Q, KK_, R_>), grid, dim3(256), lds, s, in, w, scale, shift, y, Cout, H, W, dilation, \
+                       relu, (int)ntasks, tasks_per_img, cin)
+            if (cop == 4) { if (k == 3) GOM(1, 3, 4); else GOM(1, 1, 4); }
+            else if (cop == 8) { if (k == 3) GOM(2, 3, 4); else GOM(2, 1, 4); }
+            else { if (k == 3) GOM(6, 3, 2); else GOM(6, 1, 2); }
+#undef GOM
+            return decnet_launch_status();
+        }
+    }
     if (Cout <= 1) return launch_conv<1>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s, epi, ea, eb);
     if (Cout <= 4) return launch_conv<4>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
     if (Cout <= 8) return launch_conv<8>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);

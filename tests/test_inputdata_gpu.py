@@ -3,9 +3,15 @@
 against the REFERENCE graph run on the same pixels with the shipped base_channels=8 network
 (tests/golden/inputdata/*.npz, made by tests/golden/make_inputdata_golden.py from the imported reference).  -m gpu.
 
-Gates per pair (8 cases: 4 pairs x {init17, fill} weights): (1) the GPU result is as close to the reference graph's
-FLOAT64 run as the reference's own float32 run is (ratio <= 1.25); (2) <= 1e-3 px mean abs difference to the
-reference's float32 run -- where float32 itself allows it.
+Gates per pair (8 cases: 4 pairs x {init17, fill} weights), all asserted below:
+  (1) distance to the reference graph's FLOAT64 run <= 1.5 x the distance of the reference's own float32 run
+      (measured round 4: 0.75 - 1.31; with the many-channel 2-D convolutions on the library, DECNET_CONV2D_MFMA=0,
+      0.77 - 1.00, asserted <= 1.1 in a second leg below: the excess is the bf16x3 arithmetic of csrc/conv2d_mfma.hip);
+  (2) mean abs difference to the reference's float32 run <= 1e-3 px where float32 itself allows it (the reference's own
+      float32-vs-float64 noise below 4e-4 px), <= 1e-3 + 2 x that noise otherwise -- i.e. the 1e-3 px gate IS RELAXED on
+      the noisy init17 pairs, by exactly the amount two float32 runs may differ;
+  (3) at most 10 % of the pixels set aside as flip neighbourhoods (measured: <= 3.5 %), and the ALL-PIXEL mean abs
+      difference, flipped neighbourhoods included, <= 1e-2 px (measured: <= 4.8e-3 px).
 Two caveats, both measured rather than assumed:
   * The masks are thresholded sigmoids (SparseDenseNetRefinementMask.py:163-170): a logit
     within float noise of the threshold may flip a bit, which moves that pixel (and, through the refinement
@@ -145,7 +151,8 @@ def test_inputdata_pair_matches_reference_graph(ds_name, name, variant):
     err = np.abs(pred[s3] - d["pred_s3"])                               # vs the reference's float32 run
     e_gpu64 = np.abs(pred[s3].astype(np.float64) - d["pred64_s3"])      # vs the float64 run
     e_ref64 = np.abs(d["pred_s3"].astype(np.float64) - d["pred64_s3"])  # the reference's own float32 run vs float64
-    assert clean.mean() > 0.5, "too many mask flips to judge the disparity map"
+    assert clean.mean() > 0.9, "more than 10 % of the pixels in reach of a flipped mask bit"
+    assert err.mean() < 1e-2, "all-pixel mean abs difference (flip neighbourhoods included) above 1e-2 px"
     g64, r64m = float(e_gpu64[clean].mean()), float(e_ref64[clean].mean())
     print("  final: |gpu - ref32| mean %.2e px over the %.1f%% pixels outside flip neighbourhoods (max %.2e); all pixels "
           "%.2e; |pred| mean %.1f" % (err[clean].mean(), 100 * clean.mean(), err[clean].max(), err.mean(),
@@ -156,8 +163,10 @@ def test_inputdata_pair_matches_reference_graph(ds_name, name, variant):
     #     init17 0.74 / 0.81 / 0.84 / 1.38, fill 1.20 / 1.29 / 1.32 / 1.20 x the reference's own distance; with the
     #     many-channel 2-D convolutions on the library instead of the bf16x3 matrix-core kernels 0.91 - 1.00, i.e. the
     #     excess is the six-product bf16 arithmetic of csrc/conv2d_mfma.hip (1.33 - 1.58 before its terms were rounded
-    #     to nearest instead of truncated).  Bound: 1.5 x + 2e-5 px.
-    assert g64 <= 1.5 * r64m + 2e-5, "much further from the float64 run than the reference's float32 run is"
+    #     to nearest instead of truncated).  Bound: 1.5 x + 2e-5 px; 1.1 x with those convolutions on the library
+    #     (second leg, test_fp32_trunk_is_as_close_to_float64_as_the_reference).
+    ratio_bound = float(os.environ.get("DECNET_TEST_RATIO_BOUND", "1.5"))
+    assert g64 <= ratio_bound * r64m + 2e-5, "much further from the float64 run than the reference's float32 run is"
     # (2) north_star's plain gate, 1e-3 px mean against the reference's float32 run, wherever float32 itself allows it:
     #     two float32 runs that are each e from the truth differ by up to ~2 e, so the plain gate is asserted when the
     #     reference's own float32 noise is below 4e-4 px (every "fill" pair but real/00004 at max_disp 621) and
@@ -173,3 +182,16 @@ def test_inputdata_pair_matches_reference_graph(ds_name, name, variant):
     print("  png: mean |difference| %.3f counts, %.3f%% of the sampled counts differ by more than 1, outside flip "
           "neighbourhoods" % (dp[~cl].mean(), 100 * (dp[~cl] > 1).mean()))
     assert dp[~cl].mean() < 256 * gate + 0.5      # both sides truncate to 1/256 px
+
+
+def test_fp32_trunk_is_as_close_to_float64_as_the_reference():
+    """Second leg: with the many-channel 2-D convolutions on the library's fp32 kernels
+    (DECNET_CONV2D_MFMA=0; the switch is read once per process, hence the child) the graph must be as close to the
+    float64 run as the reference's own float32 run: ratio <= 1.1 (measured 0.77 - 1.00) on three pairs.  A regression of
+    the fp32 kernels (SpaMat / SpaVar, stage 0, the few-channel convolutions) shows here without the bf16x3 noise."""
+    import subprocess
+    env = dict(os.environ, DECNET_CONV2D_MFMA="0", DECNET_TEST_RATIO_BOUND="1.1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "pair_matches and (Sceneflow-0006-fill or KITTI-000009_10-fill or real-00004-init17)"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
