@@ -447,3 +447,31 @@ def test_randomized_densities_around_the_path_boundaries(dev):
         np.testing.assert_allclose(fo.cpu().numpy(), o, rtol=1e-5, atol=3e-4, err_msg=tag)
         np.testing.assert_allclose(fs.cpu().numpy(), s, rtol=2e-5, atol=1e-9, err_msg=tag)
         np.testing.assert_allclose(fv.cpu().numpy(), v, rtol=2e-4, atol=2e-2, err_msg=tag)
+
+
+def test_graphed_step_replays_forward_and_backward(dev):
+    """decnet_amd.graphs.GraphedStep: SpaMatFunction forward + backward of two stages captured once into a HIP graph;
+    a replay after changing the inputs IN PLACE gives the gradients of an eager run on the new values."""
+    import decnet_amd
+    from decnet_amd.graphs import GraphedStep
+    mod = decnet_amd.SpaMat()
+    items = []
+    for seed, (B, C, H, W, D, p) in enumerate([(2, 8, 6, 300, 216, 0.6), (2, 24, 5, 81, 72, 1.0)]):
+        L, R, rm, tm = make_case(40 + seed, B, C, H, W, p, p, relu=False, scale=0.5)
+        g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(seed))
+        items.append([L.to(dev).requires_grad_(), R.to(dev).requires_grad_(), rm.to(dev), tm.to(dev), D, g.to(dev)])
+
+    def whole():
+        return [mod(a, b, c, d, D).backward(g) for (a, b, c, d, D, g) in items]
+    step = GraphedStep(whole, grads_of=[t for it in items for t in it[:2]])
+    with torch.no_grad():                                 # new values, same storage
+        for it in items:
+            it[0].mul_(0.75)
+            it[1].add_(0.1)
+    step()
+    torch.cuda.synchronize()
+    got = [(it[0].grad.clone(), it[1].grad.clone()) for it in items]
+    for it, (gl, gr) in zip(items, got):
+        a, b = it[0].detach().clone().requires_grad_(), it[1].detach().clone().requires_grad_()
+        mod(a, b, it[2], it[3], it[4]).backward(it[5])
+        assert torch.equal(a.grad, gl) and torch.equal(b.grad, gr)
