@@ -678,6 +678,8 @@ def main():
                     help="no GPU: exercise the N-rank launch, sharding and collectives on gloo (value null)")
     ap.add_argument("--mask-density", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0,
+                    help="seconds of host work the cpu_baseline leg may take (its sample says what it covered)")
     ap.add_argument("--no-density-sweep", action="store_true",
                     help="skip the extra cost-volume timings at mask densities 0.3 .. 0.02 (PMC passes: keeps "
                          "every launch of a kernel the same work)")
@@ -973,7 +975,7 @@ def main():
                 os.environ.get("DECNET_WINO_GEMM", "") == ""):
             out["alt_wino_gemm_fp32"] = alt_gemm_leg()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)
         print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()

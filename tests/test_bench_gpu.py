@@ -24,7 +24,7 @@ def _run(*flags, live_traffic=False):
 
 
 def test_bench_line_contract():
-    d = _run("--no-e2e", "--no-train", "--no-density-sweep")
+    d = _run("--no-e2e", "--no-train", "--no-density-sweep", "--cpu-budget", "2")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
