@@ -629,238 +629,283 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? 4 : 2)) void spamat_bwd_sparse
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dense rows, C <= 8, SpaMat (round 4): BOTH gradients from ONE pass over the cost / weight tiles.
-// The two band launches above form every 16 x 16 cost tile, its exponentials and weights twice (once per side) and
-// each reads both feature rows: stage 3, B = 4: 0.75 ms, 1.63 x the algorithmic bytes.  Here ONE WAVE OWNS ONE ROW and
-// walks its left tiles xt = 0, 1, ... in order.  For the tile pair (left tile xt, right tile xt - m):
-//   cost (2 fp32 MFMAs, rows = right pixels 4q + r, columns = left pixels j) -> weight w = e (d - out)      [once]
-//   gL[c][left]  += sum_right w R[c][right]     the weight registers are the MFMA operand as in spamat_bwd_mfma
-//   gR[c][right] += sum_left  w g/S L[c][left]  needs the TRANSPOSED tile as operand: four ds_write_b32 + one
-//                                               ds_read_b128 through a 1.25 KB per-wave scratch (in-order LDS, no barrier)
-// gL of a left tile is complete after its NT band tiles.  gR of a right tile collects from the NT left tiles xt .. xt +
-// NT - 1: the wave keeps a WINDOW of NT accumulator tiles gr[m] (right tile xt - m) in registers, stores gr[NT - 1]
-// when left tile xt is done and shifts the window by one -- no atomics, no cross-wave reduction, a fixed summation
-// order.  Nothing but a ring of the last NT right tiles (features [8][NT * 16], mask bias) lives in LDS; every input
-// byte is read once and every gradient byte written once.  Reference semantics: SM_kernel.cu:143-195 (ref), 300-355 (tar).
-constexpr int ROW_TSP = 20;                               // pitch of the transposition scratch (floats)
+// Dense rows, C <= 8, SpaMat (round 4): BOTH gradients from ONE pass over the cost / weight tiles (spamat_bwd_roww below).
+// The two band launches above form every 16 x 16 cost tile, its exponentials and weights twice (once per side) and each
+// reads both feature rows: stage 3, B = 4: 0.75 ms, 1.63 x the algorithmic bytes.  One pass needs the weight tile
+//   w = e (d - out)    (rows = right pixels, columns = left pixels; SM_kernel.cu:191)
+// in both orientations:  gL[c][left] += sum_right w R[c][right]  and  gR[c][right] += sum_left w g/S L[c][left]
+// (SM_kernel.cu:143-195, 300-355), and gR of a right tile collects from the NT left tiles xt .. xt + NT - 1.
+// Three forms were built and measured at stage 3 (B = 4 / B = 8, backward through the autograd Function; the band
+// launches: 0.81 / 1.53 ms); the first two are in the repository's history (commit "one-pass dense-row SpaMat backward"):
+//   one wave per row, contractions on v_mfma_f32_16x16x4_f32, a window of NT accumulator tiles      0.80 / 1.33 ms
+//   the same with the contractions on v_mfma_f32_4x4x1_16B_f32 (half the contraction cycles)          0.72 / 1.33 ms
+//   four waves per row, each owning the right tiles t = w (mod 4) (below)                             0.55 / 1.00 ms
+// The first two are bound by the single wave's dependency chain (cost MFMA -> weights -> LDS round trip -> contraction,
+// 15 tiles per left tile) at 3 waves per SIMD; halving their MFMA cycles changed nothing.
 constexpr int ROW_RING = 16;                              // ring of right tiles (>= NT, a power of two)
 constexpr int ROW_RP = ROW_RING * 16 + 4;                 // feature ring pitch == 4 (mod 64)
-constexpr int ROW_LDS_FLOATS = 8 * ROW_RP + ROW_RING * 16 + 2 * 16 * ROW_TSP;
 
-#ifndef DECNET_BWD_ROW_PIPE
-#define DECNET_BWD_ROW_PIPE 1
+// ---- the contractions: v_mfma_f32_4x4x1_16B_f32 (no channel padding) ---------------------------------------------------
+// On the 16 x 16 x 4 instruction the contractions would land on 16 channel columns of which C = 8 exist.  The 4 x 4 x 1
+// instruction (16 independent 4 x 4 outer products per wave-instruction, K = 1; tools/ubench/mfma4x4.hip: 10 cycles per
+// instruction from two accumulator chains) has no such padding: block b = lane / 4 = (kh, g, cg) takes
+//     left gradient:  rows i = left pixels 4g + i, columns e = channels 4cg + e, K = the 8 right pixels 8kh .. 8kh + 7
+//     right gradient: rows i = right pixels 4g + i, columns e = channels 4cg + e, K = the 8 left pixels 8kh .. 8kh + 7
+// i.e. 16 x 8 outputs x two K halves per instruction, 8 instructions per contraction (64 cycles against 128), the two
+// halves added once per tile column (one cross-half shuffle of four registers).  The weight tile comes out of the
+// 16 x 16 x 4 cost MFMAs (lane (j, q), register r = right pixel 4q + r, left pixel j) and goes through LDS in both
+// orientations -- TL[left][right] by one ds_write_b128, TR[right][left] by four ds_write_b32 (per-wave scratch, in-order
+// LDS: no barrier) -- so that every lane reads its 8 A values of a contraction with two ds_read_b128; the B values are two
+// ds_read_b128 of the feature ring (left gradient) or eight registers per left tile (right gradient: g/S-scaled left
+// features, staged once per left tile).
+constexpr int ROW4_TP = 20;                               // pitch of the two weight-tile copies (floats; rows 16-byte aligned)
+
+// ---- four waves per row -----------------------------------------------------------------------------------------------
+// A 256-thread workgroup owns the row and wave w owns the RIGHT tiles t = w (mod 4): for left tile xt it forms the (at
+// most four) band tiles m = xt - t of its right tiles, so its right-gradient window is 4 accumulator tiles, not NT (a
+// right tile keeps its owner while xt advances; the window slides when m0 = (xt - w) mod 4 wraps; the tile at
+// m = NT - 1 is complete and stored), the per-wave dependency chain is 4 tiles long and 4 waves fit a SIMD without
+// spills.  Shared by the workgroup: the ring of the last 16 right tiles (features [8][RP], mask bias), the g/S-scaled
+// left features and g/S of the current left tile (committed by wave 0 from registers it fetched one tile ahead; barrier
+// 1), and the four partial left gradients of a left tile (barrier 2; summed in a fixed wave order by 32 lanes of wave
+// xt mod 4, which also stores them).  Right tiles left of the row are skipped; nothing is atomic, every input byte is
+// read once, every gradient byte written once.
+#ifndef DECNET_BWD_ROWW_NW
+#define DECNET_BWD_ROWW_NW 4           // waves per row of spamat_bwd_roww (4 or 8)
 #endif
-#ifndef DECNET_BWD_ROW_WPE
-#define DECNET_BWD_ROW_WPE 3          // waves per SIMD the register allocation of spamat_bwd_row is held to (measured: 1: 1.30,
-                                      // 2: 0.90, 3: 0.80 ms at stage 3, B = 4; the two band launches: 0.82)
+#ifndef DECNET_BWD_ROWW_PRE
+#define DECNET_BWD_ROWW_PRE 0
 #endif
+#ifndef DECNET_BWD_ROWW_OCC
+#define DECNET_BWD_ROWW_OCC 4          // waves per SIMD the register allocation is held to (measured at stage 3, B = 4:
+                                      // unconstrained (162 registers, 3 waves) 0.63 ms, 4: 0.55, 5 (spills): 0.75; 8 waves per row: 0.68)
+#endif
+constexpr int ROWW_NW = DECNET_BWD_ROWW_NW;
+constexpr int ROWW_LDS_FLOATS = 8 * ROW_RP + ROW_RING * 16 + ROWW_NW * 2 * 16 * ROW4_TP + 8 * 16 + 16 + ROWW_NW * 128;
+
 template <int NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DECNET_BWD_ROW_WPE, DECNET_BWD_ROW_WPE))) void spamat_bwd_row(
+__global__ __launch_bounds__(64 * ROWW_NW, DECNET_BWD_ROWW_OCC) void spamat_bwd_roww(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ out, const float *__restrict__ sum_sim,
     const float *__restrict__ max_cost, const float *__restrict__ grad_out, float *__restrict__ grad_ref,
     float *__restrict__ grad_tar, int C, int H, int W, int D, int marker) {
     static_assert(NT <= ROW_RING, "band wider than the ring");
-    constexpr int RP = ROW_RP;
-    __shared__ __attribute__((aligned(16))) float smem[ROW_LDS_FLOATS];
+    constexpr int RP = ROW_RP, TP = ROW4_TP, NW = ROWW_NW, KS = (NT + NW - 1) / NW, NTHR = 64 * NW;
+    __shared__ __attribute__((aligned(16))) float smem[ROWW_LDS_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *RF = smem;                                    // [8][RP]: right features of the last 16 tiles (ring)
     float *BZ = smem + 8 * RP;                           // [16 * 16]: 0 / -1e30 of the right mask (ring)
-    float *TS = BZ + ROW_RING * 16;                      // 2 x [16][ROW_TSP]: weight tiles, rows = right pixels
+    float *TL = BZ + ROW_RING * 16 + wave * 2 * 16 * TP; // this wave's weight tile, rows = left pixels
+    float *TR = TL + 16 * TP;                            // ... rows = right pixels
+    float *LQ = smem + 8 * RP + ROW_RING * 16 + NW * 2 * 16 * TP;   // [8][16]: g/S-scaled left features of the left tile
+    float *GS = LQ + 8 * 16;                             // [16]: g/S of the left tile's pixels
+    float *GLP = GS + 16;                                // [4 waves][32 lanes][4]: partial left gradients
     const int row = blockIdx.x, b = row / H, y = row - b * H;
     const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
     const size_t frow = ((size_t)b * C * H + y) * W;
-    if (marker && __float_as_int(grad_ref[frow]) != BWD_MARK) return;    // the sparse-row launches took this row
+    if (marker && __float_as_int(grad_ref[frow]) != BWD_MARK) return;    // (block-uniform) the sparse-row launches took this row
     const float *lrow = ref + frow, *rrow = tar + frow;
     float *glrow = grad_ref + frow, *grrow = grad_tar + frow;
-    const int lane = threadIdx.x, j = lane & 15, q = lane >> 4;
+    const int j = lane & 15, q = lane >> 4;              // cost-tile coordinates
+    const int e4 = lane & 3, cg = (lane >> 2) & 1, g4 = (lane >> 3) & 3, kh = lane >> 5;   // contraction coordinates
+    const int cc4 = 4 * cg + e4;
     const int XT = (W + 15) >> 4;
-    const bool al4 = (W & 3) == 0 && ((((uintptr_t)ref) | ((uintptr_t)rmask) | ((uintptr_t)sum_sim) |
-                                       ((uintptr_t)grad_out) | ((uintptr_t)grad_ref)) & 15) == 0;
-    const int cj = j < C ? j : C - 1;                    // channel this lane supplies to / owns in the contractions
-    // right tiles left of the row (xt - m < 0) are walked like any other: zero features, mask off -> weights 0
-    for (int i = lane; i < 8 * RP; i += 64) RF[i] = 0.f;
-    for (int i = lane; i < ROW_RING * 16; i += 64) BZ[i] = NEG_BIG;
+    const bool al4 = (W & 3) == 0 && ((((uintptr_t)grad_ref) | ((uintptr_t)grad_tar)) & 15) == 0;
+    for (int i = threadIdx.x; i < 8 * RP; i += NTHR) RF[i] = 0.f;         // tiles left of the row: zero features, mask off
+    for (int i = threadIdx.x; i < ROW_RING * 16; i += NTHR) BZ[i] = NEG_BIG;
 
-    // "next tile" registers: everything left tile xt + 1 needs from HBM is requested while tile xt is computed
-    float nR[2], nL[2], nTm, nMax, nOut, nRm;
-    float4 nLq, nG4, nS4, nM4;
+    const int lc = lane >> 3, lp = 2 * (lane & 7);       // wave 0's staging of LQ / GS: (channel, pixel pair)
+    float nR[2], nL[2], nTm = 0.f, nMax, nOut, nRm, nL2[2], nG2[2], nS2[2], nM2[2];
     auto fetch = [&](int xt) {
-        const int x = xt * 16 + j, xq = xt * 16 + 4 * q;
+        const int x = xt * 16 + j;
         const bool ok = xt < XT && x < W;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bool okc = ok && 4 * s + q < C;
-            nR[s] = okc ? rrow[(size_t)(4 * s + q) * plane + x] : 0.f;
-            nL[s] = okc ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
-        }
-        nTm = ok ? tmask[rowpix + x] : 0.f;
+        for (int s = 0; s < 2; ++s) nL[s] = (ok && 4 * s + q < C) ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
         nRm = ok ? rmask[rowpix + x] : 0.f;
         nMax = ok ? max_cost[rowpix + x] : 0.f;
         nOut = ok ? out[rowpix + x] : 0.f;
-        const bool okq = xt < XT;
-        nLq = okq ? load4(lrow + (size_t)cj * plane, xq, W, al4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        nG4 = okq ? load4(grad_out + rowpix, xq, W, al4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        nS4 = okq ? load4(sum_sim + rowpix, xq, W, al4) : make_float4(1.f, 1.f, 1.f, 1.f);
-        nM4 = okq ? load4(rmask + rowpix, xq, W, al4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave == 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) nR[s] = (ok && 4 * s + q < C) ? rrow[(size_t)(4 * s + q) * plane + x] : 0.f;
+            nTm = ok ? tmask[rowpix + x] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int xp = xt * 16 + lp + u;
+                const bool okp = xt < XT && xp < W;
+                nL2[u] = (okp && lc < C) ? lrow[(size_t)lc * plane + xp] : 0.f;
+                nG2[u] = okp ? grad_out[rowpix + xp] : 0.f;
+                nS2[u] = okp ? sum_sim[rowpix + xp] : 1.f;
+                nM2[u] = okp ? rmask[rowpix + xp] : 0.f;
+            }
+        }
     };
     fetch(0);
 
-    f32x4 gr[NT];                                        // gr[m]: right tile xt - m; [r] = channel 4q + r, lane j = pixel
+    f32x4 gr[KS];                        // gr[k]: right tile xt - (m0 + 4k); lane (kh, g, cg, e), register i: pixel 4g + i, channel 4cg + e
 #pragma unroll
-    for (int m = 0; m < NT; ++m) gr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // channel 4q + r of right tile t (complete) -> grad_tar, 0 where the right mask is off (SpaMat.py:43)
-    auto store_right = [&](int t, const f32x4 &g) {
-        const int x = t * 16 + j;
-        if (t < 0 || x >= W) return;
-        const bool on = BZ[(t & (ROW_RING - 1)) * 16 + j] == 0.f;
+    for (int k = 0; k < KS; ++k) gr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto xhalf = [&](f32x4 v) {                          // + the other K half's partial sums (lane ^ 32)
+        f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * q + r < C) grrow[(size_t)(4 * q + r) * plane + x] = on ? g[r] : 0.f;
+        for (int r = 0; r < 4; ++r) o[r] = v[r] + __shfl_xor(v[r], 32);
+        return o;
     };
-    const int tsw = j, tsr = j * ROW_TSP + 4 * q;       // scratch: write column / read row of this lane
+    auto store_right = [&](int t, const f32x4 &gpart) {  // right tile t complete -> grad_tar (0 where the right mask is off)
+        if (t < 0) return;                               // (wave-uniform)
+        const f32x4 gsum = xhalf(gpart);
+        const int x = t * 16 + 4 * g4;
+        if (kh != 0 || cc4 >= C || x >= W) return;
+        const float4 bz = *reinterpret_cast<const float4 *>(BZ + (t & (ROW_RING - 1)) * 16 + 4 * g4);
+        float *gp = grrow + (size_t)cc4 * plane + x;
+        const float o[4] = {bz.x == 0.f ? gsum[0] : 0.f, bz.y == 0.f ? gsum[1] : 0.f, bz.z == 0.f ? gsum[2] : 0.f,
+                            bz.w == 0.f ? gsum[3] : 0.f};
+        if (al4 && x + 3 < W) {
+            *reinterpret_cast<float4 *>(gp) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (x + r < W) gp[r] = o[r];
+        }
+    };
+    __syncthreads();                                     // the zeroed ring
 
     for (int xt = 0; xt < XT; ++xt) {
         const int x0 = xt * 16, s0 = xt & (ROW_RING - 1);
-        // commit tile xt: right features + mask bias into the ring (the slot held right tile xt - 16: dead), own operands
-        RF[q * RP + s0 * 16 + j] = nR[0];
-        RF[(q + 4) * RP + s0 * 16 + j] = nR[1];
-        if (q == 0) BZ[s0 * 16 + j] = nTm != 0.f ? 0.f : NEG_BIG;
-        const float bcur[2] = {nL[0], nL[1]};
-        // a masked-off (or out-of-row) left pixel takes part in no candidate: exp2(cost - 1e30) = 0
-        const float nm_own = nRm != 0.f ? -nMax * LOG2E : NEG_BIG;
-        const float out_own = nOut;
-        float gs[4];                                     // g / S of left pixels x0 + 4q + r, 0 where the left mask is off
-        {
-            const float g4[4] = {nG4.x, nG4.y, nG4.z, nG4.w}, s4[4] = {nS4.x, nS4.y, nS4.z, nS4.w},
-                        m4[4] = {nM4.x, nM4.y, nM4.z, nM4.w};
+        const int m0 = (xt - wave) & (NW - 1);           // this wave's band tiles: m0, m0 + NW, ...
+        if (xt > 0 && m0 == 0) {                         // the window slides: a new right tile (t = xt) enters at k = 0
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gs[r] = (x0 + 4 * q + r < W && m4[r] != 0.f) ? g4[r] / s4[r] : 0.f;
+            for (int k = KS - 1; k > 0; --k) gr[k] = gr[k - 1];
+            gr[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // A operand of the right-gradient contraction: g/S L[c = j][x0 + 4q + r] (SM_kernel.cu:346), 0 for j >= C
-        const float lq[4] = {j < C ? nLq.x * gs[0] : 0.f, j < C ? nLq.y * gs[1] : 0.f, j < C ? nLq.z * gs[2] : 0.f,
-                             j < C ? nLq.w * gs[3] : 0.f};
+        if (wave == 0) {                                 // commit tile xt (ring slot s0 held right tile xt - 16: dead)
+            RF[q * RP + s0 * 16 + j] = nR[0];
+            RF[(q + 4) * RP + s0 * 16 + j] = nR[1];
+            if (q == 0) BZ[s0 * 16 + j] = nTm != 0.f ? 0.f : NEG_BIG;
+            float gsv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gsv[u] = nM2[u] != 0.f ? nG2[u] / nS2[u] : 0.f;   // g / S, 0 where the left mask is off
+            LQ[lc * 16 + lp] = nL2[0] * gsv[0];          // SM_kernel.cu:346: g/S L[c][left]
+            LQ[lc * 16 + lp + 1] = nL2[1] * gsv[1];
+            if (lc == 0) { GS[lp] = gsv[0]; GS[lp + 1] = gsv[1]; }
+        }
+        const float bcur[2] = {nL[0], nL[1]};
+        const float nm_own = nRm != 0.f ? -nMax * LOG2E : NEG_BIG;   // masked-off / out-of-row left pixel: weights 0
+        const float out_own = nOut;
         fetch(xt + 1);
+        __syncthreads();                                 // (1) tile xt is in the ring, LQ / GS are this left tile's
+        const float4 lq0 = *reinterpret_cast<const float4 *>(LQ + cc4 * 16 + 8 * kh);
+        const float4 lq1 = *reinterpret_cast<const float4 *>(LQ + cc4 * 16 + 8 * kh + 4);
+        const float lqv[8] = {lq0.x, lq0.y, lq0.z, lq0.w, lq1.x, lq1.y, lq1.z, lq1.w};
         const float dj = (float)(j - 4 * q) - out_own;   // d - out = 16 m - r + dj
         f32x4 gl = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // Software pipeline over the band (fully unrolled, one basic block): while the matrix pipe forms the cost tile of
-        // m + 1 the VALU turns the cost tile of m into weights; the transposed weights of m are read back one step later,
-        // behind the left-gradient MFMAs of m and the weights of m + 1 (two scratch tiles).
-        auto ring = [&](int m) { return ((xt - m) & (ROW_RING - 1)) * 16; };
-        auto cost = [&](int m) {
-            const int ob = ring(m);
-            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[q * RP + ob + j], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            return __builtin_amdgcn_mfma_f32_16x16x4f32(RF[(q + 4) * RP + ob + j], bcur[1], c, 0, 0, 0);
-        };
-#if DECNET_BWD_ROW_PIPE
-        f32x4 cst = cost(0);
-        float4 tw_prev = make_float4(0.f, 0.f, 0.f, 0.f);
+#if DECNET_BWD_ROWW_PRE
+        // all cost tiles of this wave first: up to KS independent MFMA pairs in flight before the first weight is formed
+        f32x4 cpre[KS];
 #pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            const int ob = ring(m);
-            f32x4 cst_next = cst;
-            if (m + 1 < NT) cst_next = cost(m + 1);
-            const float4 bz = *reinterpret_cast<const float4 *>(BZ + ob + 4 * q);
-            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
-            const bool edge = m == 0 || 16 * m + 15 >= D;             // tiles that leave 0 <= d < D
-            f32x4 wt;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float cc = cst[r] + bzv[r];
-                if (edge) {
-                    const int d = 16 * m + j - (4 * q + r);
-                    cc = (unsigned)d < (unsigned)D ? cc : NEG_BIG;
-                }
-                const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm_own));
-                wt[r] = e * ((float)(16 * m - r) + dj);               // SM_kernel.cu:191
-            }
-            float *ts = TS + (m & 1) * 16 * ROW_TSP;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ts[(4 * q + r) * ROW_TSP + tsw] = wt[r];
-            // left gradient: contraction over the tile's 16 right pixels (K step r <-> right pixel 4q + r)
-            const float4 ov = *reinterpret_cast<const float4 *>(RF + cj * RP + ob + 4 * q);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0], ov.x, gl, 0, 0, 0);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1], ov.y, gl, 0, 0, 0);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[2], ov.z, gl, 0, 0, 0);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[3], ov.w, gl, 0, 0, 0);
-            // right gradient of the PREVIOUS band tile: its transposed weights (rows = right pixels) are the B operand,
-            // K step r <-> left pixel 4q + r
-            if (m > 0) {
-                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[0], tw_prev.x, gr[m - 1], 0, 0, 0);
-                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[1], tw_prev.y, gr[m - 1], 0, 0, 0);
-                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[2], tw_prev.z, gr[m - 1], 0, 0, 0);
-                gr[m - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[3], tw_prev.w, gr[m - 1], 0, 0, 0);
-            }
-            tw_prev = *reinterpret_cast<const float4 *>(ts + tsr);
-            cst = cst_next;
-        }
-        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[0], tw_prev.x, gr[NT - 1], 0, 0, 0);
-        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[1], tw_prev.y, gr[NT - 1], 0, 0, 0);
-        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[2], tw_prev.z, gr[NT - 1], 0, 0, 0);
-        gr[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[3], tw_prev.w, gr[NT - 1], 0, 0, 0);
-#else
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            if (m > xt) continue;                        // right tile left of the row (uniform)
-            const int ob = ring(m);
-            const f32x4 cst = cost(m);
-            const float4 bz = *reinterpret_cast<const float4 *>(BZ + ob + 4 * q);
-            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
-            const bool edge = m == 0 || 16 * m + 15 >= D;             // tiles that leave 0 <= d < D
-            f32x4 wt;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float cc = cst[r] + bzv[r];
-                if (edge) {
-                    const int d = 16 * m + j - (4 * q + r);
-                    cc = (unsigned)d < (unsigned)D ? cc : NEG_BIG;
-                }
-                const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm_own));
-                wt[r] = e * ((float)(16 * m - r) + dj);               // SM_kernel.cu:191
-            }
-            float *ts = TS + (m & 1) * 16 * ROW_TSP;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ts[(4 * q + r) * ROW_TSP + tsw] = wt[r];
-            const float4 ov = *reinterpret_cast<const float4 *>(RF + cj * RP + ob + 4 * q);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0], ov.x, gl, 0, 0, 0);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1], ov.y, gl, 0, 0, 0);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[2], ov.z, gl, 0, 0, 0);
-            gl = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[3], ov.w, gl, 0, 0, 0);
-            const float4 tw = *reinterpret_cast<const float4 *>(ts + tsr);
-            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[0], tw.x, gr[m], 0, 0, 0);
-            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[1], tw.y, gr[m], 0, 0, 0);
-            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[2], tw.z, gr[m], 0, 0, 0);
-            gr[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[3], tw.w, gr[m], 0, 0, 0);
+        for (int k = 0; k < KS; ++k) {
+            const int m = m0 + NW * k;
+            const int ob = ((xt - m) & (ROW_RING - 1)) * 16;
+            cpre[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[q * RP + ob + j], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            cpre[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[(q + 4) * RP + ob + j], bcur[1], cpre[k], 0, 0, 0);
         }
 #endif
-        // gl[r]: channel j, left pixel x0 + 4q + r: grad_ref = g * sum / S (SM_kernel.cu:193); masked-off pixels 0
-        if (j < C) {
-            float *gp = glrow + (size_t)j * plane + x0 + 4 * q;
-            if (al4 && x0 + 4 * q + 3 < W) {
-                *reinterpret_cast<float4 *>(gp) = make_float4(gl[0] * gs[0], gl[1] * gs[1], gl[2] * gs[2], gl[3] * gs[3]);
-            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (x0 + 4 * q + r < W) gp[r] = gl[r] * gs[r];
+        for (int k = 0; k < KS; ++k) {
+            const int m = m0 + NW * k;
+            if (m >= NT || m > xt) continue;             // (wave-uniform) outside the band / left of the row
+            const int ob = ((xt - m) & (ROW_RING - 1)) * 16;
+#if DECNET_BWD_ROWW_PRE
+            const f32x4 cst = cpre[k];
+#else
+            f32x4 cst = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[q * RP + ob + j], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            cst = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[(q + 4) * RP + ob + j], bcur[1], cst, 0, 0, 0);
+#endif
+            const float4 rb0 = *reinterpret_cast<const float4 *>(RF + cc4 * RP + ob + 8 * kh);
+            const float4 rb1 = *reinterpret_cast<const float4 *>(RF + cc4 * RP + ob + 8 * kh + 4);
+            const float4 bz = *reinterpret_cast<const float4 *>(BZ + ob + 4 * q);
+            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+            const float dm = (float)(16 * m) + dj;
+            f32x4 wt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * m + j - (4 * q + r);
+                float cc = cst[r] + bzv[r];
+                cc = (unsigned)d < (unsigned)D ? cc : NEG_BIG;            // 0 <= d < D (edge tiles of the band)
+                const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm_own));
+                wt[r] = e * (dm - (float)r);                              // SM_kernel.cu:191
+            }
+            *reinterpret_cast<float4 *>(TL + j * TP + 4 * q) = make_float4(wt[0], wt[1], wt[2], wt[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) TR[(4 * q + r) * TP + j] = wt[r];
+            // left gradient: A = W[right 8kh + s][left 4g + e], B = R[4cg + e][right 8kh + s]
+            {
+                const float4 a0 = *reinterpret_cast<const float4 *>(TL + (4 * g4 + e4) * TP + 8 * kh);
+                const float4 a1 = *reinterpret_cast<const float4 *>(TL + (4 * g4 + e4) * TP + 8 * kh + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float bv[8] = {rb0.x, rb0.y, rb0.z, rb0.w, rb1.x, rb1.y, rb1.z, rb1.w};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) gl = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], bv[s], gl, 0, 0, 0);
+            }
+            // right gradient: A = W[right 4g + e][left 8kh + s], B = g/S L[4cg + e][left 8kh + s]
+            {
+                const float4 a0 = *reinterpret_cast<const float4 *>(TR + (4 * g4 + e4) * TP + 8 * kh);
+                const float4 a1 = *reinterpret_cast<const float4 *>(TR + (4 * g4 + e4) * TP + 8 * kh + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) gr[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], lqv[s], gr[k], 0, 0, 0);
+            }
+            if (m == NT - 1) {                           // right tile xt - m has seen all its left tiles
+                store_right(xt - m, gr[k]);
+                gr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        // right tile xt - (NT - 1) has seen all its left tiles: store, then slide the window
-        store_right(xt - (NT - 1), gr[NT - 1]);
+        // this wave's share of the left tile's gradient -> LDS; summed in wave order by wave xt mod 4
+        {
+            const f32x4 gsum = xhalf(gl);
+            if (kh == 0) *reinterpret_cast<float4 *>(GLP + wave * 128 + lane * 4) = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
+        }
+        float4 gs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave == (xt & (NW - 1)) && kh == 0) gs4 = *reinterpret_cast<const float4 *>(GS + 4 * g4);
+        __syncthreads();                                 // (2) partials complete; LQ / GS / the ring slot may be overwritten
+        if (wave == (xt & (NW - 1)) && kh == 0) {
+            float4 acc = *reinterpret_cast<const float4 *>(GLP + lane * 4);
 #pragma unroll
-        for (int m = NT - 1; m > 0; --m) gr[m] = gr[m - 1];
-        gr[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int w2 = 1; w2 < NW; ++w2) {
+                const float4 p2 = *reinterpret_cast<const float4 *>(GLP + w2 * 128 + lane * 4);
+                acc.x += p2.x; acc.y += p2.y; acc.z += p2.z; acc.w += p2.w;
+            }
+            // lane (g, cg, e): left pixels x0 + 4g + i, channel 4cg + e: grad_ref = g * sum / S (SM_kernel.cu:193)
+            const int x = x0 + 4 * g4;
+            if (cc4 < C && x < W) {
+                float *gp = glrow + (size_t)cc4 * plane + x;
+                const float o[4] = {acc.x * gs4.x, acc.y * gs4.y, acc.z * gs4.z, acc.w * gs4.w};
+                if (al4 && x + 3 < W) {
+                    *reinterpret_cast<float4 *>(gp) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (x + r < W) gp[r] = o[r];
+                }
+            }
+        }
     }
-    // the last NT - 1 right tiles: after the final slide gr[m] holds right tile XT - m (m >= 1)
+    // right tiles still open after the last left tile (those at m = NT - 1 were stored in the loop)
+    {
+        const int m0 = (XT - 1 - wave) & (NW - 1);
 #pragma unroll
-    for (int m = 1; m < NT; ++m) store_right(XT - m, gr[m]);
+        for (int k = 0; k < KS; ++k) {
+            const int m = m0 + NW * k;
+            if (m < NT - 1) store_right(XT - 1 - m, gr[k]);
+        }
+    }
 }
 
 template <int NT>
 int launch_row(const float *ref, const float *tar, const float *rmask, const float *tmask, const float *out,
                const float *sum_sim, const float *max_cost, const float *grad_out, float *grad_ref, float *grad_tar,
                int B, int C, int H, int W, int D, int marker, hipStream_t stream) {
-    hipLaunchKernelGGL((spamat_bwd_row<NT>), dim3((unsigned)((size_t)B * H)), dim3(64), 0, stream, ref, tar, rmask, tmask,
-                       out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, C, H, W, D, marker);
+    hipLaunchKernelGGL((spamat_bwd_roww<NT>), dim3((unsigned)((size_t)B * H)), dim3(64 * ROWW_NW), 0, stream, ref, tar, rmask,
+                       tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, C, H, W, D, marker);
     return decnet_launch_status();
 }
 
