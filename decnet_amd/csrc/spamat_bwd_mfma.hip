@@ -673,9 +673,6 @@ constexpr int ROW4_TP = 20;                               // pitch of the two we
 #ifndef DECNET_BWD_ROWW_NW
 #define DECNET_BWD_ROWW_NW 4           // waves per row of spamat_bwd_roww (4 or 8)
 #endif
-#ifndef DECNET_BWD_ROWW_PRE
-#define DECNET_BWD_ROWW_PRE 0
-#endif
 #ifndef DECNET_BWD_ROWW_OCC
 #define DECNET_BWD_ROWW_OCC 4          // waves per SIMD the register allocation is held to (measured at stage 3, B = 4:
                                       // unconstrained (162 registers, 3 waves) 0.63 ms, 4: 0.55, 5 (spills): 0.75; 8 waves per row: 0.68)
@@ -798,28 +795,13 @@ __global__ __launch_bounds__(64 * ROWW_NW, DECNET_BWD_ROWW_OCC) void spamat_bwd_
         const float lqv[8] = {lq0.x, lq0.y, lq0.z, lq0.w, lq1.x, lq1.y, lq1.z, lq1.w};
         const float dj = (float)(j - 4 * q) - out_own;   // d - out = 16 m - r + dj
         f32x4 gl = f32x4{0.f, 0.f, 0.f, 0.f};
-#if DECNET_BWD_ROWW_PRE
-        // all cost tiles of this wave first: up to KS independent MFMA pairs in flight before the first weight is formed
-        f32x4 cpre[KS];
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const int m = m0 + NW * k;
-            const int ob = ((xt - m) & (ROW_RING - 1)) * 16;
-            cpre[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[q * RP + ob + j], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            cpre[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[(q + 4) * RP + ob + j], bcur[1], cpre[k], 0, 0, 0);
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int m = m0 + NW * k;
             if (m >= NT || m > xt) continue;             // (wave-uniform) outside the band / left of the row
             const int ob = ((xt - m) & (ROW_RING - 1)) * 16;
-#if DECNET_BWD_ROWW_PRE
-            const f32x4 cst = cpre[k];
-#else
             f32x4 cst = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[q * RP + ob + j], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             cst = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[(q + 4) * RP + ob + j], bcur[1], cst, 0, 0, 0);
-#endif
             const float4 rb0 = *reinterpret_cast<const float4 *>(RF + cc4 * RP + ob + 8 * kh);
             const float4 rb1 = *reinterpret_cast<const float4 *>(RF + cc4 * RP + ob + 8 * kh + 4);
             const float4 bz = *reinterpret_cast<const float4 *>(BZ + ob + 4 * q);
