@@ -58,6 +58,7 @@ SIGNATURES = {
     "decnet_tapconv_to_chunks": [_P, _P] + [_I] * 4 + [_P],
     "decnet_tapconv_weight_floats": [_I, _I],
     "decnet_tapconv_pack_weight": [_P, _P] + [_I] * 4 + [_P],
+    "decnet_tapconv_split_weight": [_P, _I, _I, _P],
     "decnet_tap_gemm": [_P, _P, _P] + [_I] * 4 + [_P],
     "decnet_tapconv_gather": [_P, _P, _P, _P] + [_I] * 5 + [_P, _P, _P, _I, _P],
     "decnet_conv3d_cout1_workspace_floats": [_I] * 4,

@@ -1067,8 +1067,8 @@ __global__ void wino_split_weights(const float *__restrict__ U, int *__restrict_
 template <int WM, int NPAIR, int TM = 3>
 __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3 ? 1 : TM == 2 ? 3 : 2, TM > 3 ? 1 : TM == 2 ? 3 : 2))) void wino_gemm_bf16x3(
     const float *__restrict__ Vb, const int *__restrict__ Ubb, float *__restrict__ Mb, int nt, int Ci,
-    int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs) {
-    // v_ms / v_kqs, m_ms / m_kqs: bytes between consecutive tiles and between the four 4-channel groups of a
+    int Co, int np, int swz, int v_ms, int v_kqs, int m_ms, int m_kqs, int v_shared) {
+    // v_shared: every point multiplies the SAME V (decnet_tap_gemm).  v_ms / v_kqs, m_ms / m_kqs: bytes between consecutive tiles and between the four 4-channel groups of a
     // 16-channel chunk in V and in M: (64, 16) = the chunk-major layout [chunk][tile][16] of the head of this
     // file, (16, 16 nt) = the quad-major layout [chunk][4 quads][tile][4] of wino_mid_transform
     constexpr int TN = 7, OOB = 0x7fffffff, RING = 4;   // ring of 4 operand tiles: tile s + 3 (AHEAD) in flight while s is multiplied
@@ -1084,9 +1084,9 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3
     const int m0 = (mb * WM + wm) * (TM * 16);
     if (m0 >= nt) return;
     const int KC = (Ci + 15) >> 4, CG = (Co + 15) >> 4;
-    const int v_chunk = nt * 64, v_point = KC * v_chunk, m_point = CG * v_chunk;
+    const int v_chunk = nt * 64, v_point = v_shared ? 0 : KC * v_chunk, m_point = CG * v_chunk;
     const int u_term = W_BN * 64, u_pair = 3 * u_term, u_point = NPAIR * u_pair;
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, np * v_point, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (v_shared ? 1 : np) * KC * v_chunk, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)Ubb, 0, np * u_point, 0x00020000);
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc((void *)Mb, 0, np * m_point, 0x00020000);
     int v_row[TM], m_row[TM];
@@ -1221,7 +1221,7 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
         constexpr int swz = 1;                          // XCD-aware block order
         const int *Ub = reinterpret_cast<const int *>(U + (size_t)np * pad16(Ci) * W_BN);   // split copy behind U^T
         hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(nt, 96), np), dim3(256), 0, s, V, Ub, M, nt, Ci,
-                           Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16);
+                           Co, np, swz, v_quad ? 16 : 64, v_quad ? 16 * nt : 16, m_quad ? 16 : 64, m_quad ? 16 * nt : 16, 0);
         return decnet_launch_status();
     }
     if (v_quad || m_quad) return DECNET_ERR_UNSUPPORTED;
@@ -1409,7 +1409,26 @@ int decnet_tap_gemm(const float *V, const float *u, float *M, int P, int Ci, int
     if (Ci % 4 != 0 || Co > W_BN || (double)P * pad16(Ci > Co ? Ci : Co) * 4 * ntaps >= 2147483647.0 ||
         (double)ntaps * pad16(Ci) * W_BN * 4 >= 2147483647.0)
         return DECNET_ERR_UNSUPPORTED;
+    if (gemm_bf16x3() && Ci == 216) {                  // the split copy behind u: decnet_tapconv_split_weight
+        const int *Ub = reinterpret_cast<const int *>(u + (size_t)ntaps * pad16(Ci) * W_BN);
+        hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(P, 96), ntaps), dim3(256), 0, (hipStream_t)stream, V, Ub,
+                           M, P, Ci, Co, ntaps, 1, 64, 16, 64, 16, 1);
+        return decnet_launch_status();
+    }
     return launch_gemm<2>(V, u, M, P, Ci, Co, ntaps, (hipStream_t)stream, 1);
+}
+
+/* After the last decnet_tapconv_pack_weight: the bf16-term copy of all ntaps weight matrices behind the fp32 ones
+ * (u holds decnet_tapconv_weight_floats(Ci, ntaps) floats); decnet_tap_gemm reads it when Ci = 216. */
+int decnet_tapconv_split_weight(float *u, int Ci, int ntaps, void *stream) {
+    if (!u) return DECNET_ERR_NULL_POINTER;
+    if (Ci < 1 || ntaps < 1) return DECNET_ERR_BAD_SHAPE;
+    const int KC = (Ci + 15) >> 4;
+    const long nthr = (long)ntaps * ((KC + 1) / 2) * W_BN * 4;
+    if (nthr >= 2147483647L) return DECNET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(wino_split_weights, dim3(ceil_div((int)nthr, 256)), dim3(256), 0, (hipStream_t)stream, u,
+                       reinterpret_cast<int *>(u + (size_t)ntaps * pad16(Ci) * W_BN), ntaps, KC, Ci);
+    return decnet_launch_status();
 }
 
 size_t decnet_conv3d_wino_workspace_floats(int B, int D, int H, int W, int Ci, int Co, int variant) {

@@ -106,7 +106,9 @@ int decnet_tapconv_to_chunks(const float *x, float *V, int B, int Ci, int H, int
 }
 
 size_t decnet_tapconv_weight_floats(int Ci, int ntaps) {
-    return Ci < 1 || ntaps < 1 ? 0 : (size_t)ntaps * ((Ci + 15) / 16) * 16 * T_BN;
+    // fp32 U^T per tap + its bf16-term copy ([pair of chunks][3 terms][224][16] words, decnet_tapconv_split_weight)
+    const size_t kc = (Ci + 15) / 16;
+    return Ci < 1 || ntaps < 1 ? 0 : (size_t)ntaps * (kc * 16 * T_BN + ((kc + 1) / 2) * 3 * T_BN * 16);
 }
 
 /* one branch: w [Co,Ci,k,k] (k = 1 or 3) -> taps tap0 .. tap0 + k*k - 1 of u */

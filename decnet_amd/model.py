@@ -433,6 +433,7 @@ class ASPP(nn.Module):
                     sc = u.bn.weight.float() / torch.sqrt(u.bn.running_var.float() + u.bn.eps)
                     scale.append(sc)
                     shift.append(u.bn.bias.float() - u.bn.running_mean.float() * sc)
+                _lib.check(L.decnet_tapconv_split_weight(u_all.data_ptr(), ci, ntaps, st), "decnet_tapconv_split_weight")
                 torch.cuda.current_stream(dev).synchronize()          # w temporaries may go now
             self._pk = dict(u=u_all, scale=torch.cat(scale).contiguous(), shift=torch.cat(shift).contiguous(),
                             ks=ks, tap0=tap0, ntaps=ntaps, dil=[u.conv.dilation[0] for u in units])

@@ -324,7 +324,8 @@ int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w_packed, const flo
  * the ASPP block of FeatExtNetChannelPlus (submodule.py:225-241).  All branches share the input:
  *   decnet_tapconv_to_chunks   x [B,Ci,H,W] -> V [ceil(Ci/16)][P=B*H*W][16]
  *   decnet_tapconv_pack_weight one branch's w [Co,Ci,k,k] -> taps tap0.. of u (decnet_tapconv_weight_floats)
- *   decnet_tap_gemm            T[t] = V * u[t] for every tap t (fp32 MFMA), T [ntaps][ceil(Co/16)][P][16]
+ *   decnet_tapconv_split_weight after the last branch: the bf16-term copy of u behind it (read when Ci = 216)
+ *   decnet_tap_gemm            T[t] = V * u[t] for every tap t (bf16x3 / fp32 MFMA), T [ntaps][ceil(Co/16)][P][16]
  *   decnet_tapconv_gather      y[b, br*Co+co, y, x] = act(scale * sum_t T[t][co][p + offset] + shift),
  *                              taps outside the image skipped; y [B, nbranch*Co, H, W]
  * Ci % 4 == 0, Co <= 224, nbranch <= 4.
@@ -333,6 +334,7 @@ size_t decnet_tapconv_chunk_floats(int B, int Ci, int H, int W);
 int decnet_tapconv_to_chunks(const float *x, float *V, int B, int Ci, int H, int W, void *stream);
 size_t decnet_tapconv_weight_floats(int Ci, int ntaps);
 int decnet_tapconv_pack_weight(const float *w, float *u, int Co, int Ci, int k, int tap0, void *stream);
+int decnet_tapconv_split_weight(float *u, int Ci, int ntaps, void *stream);
 int decnet_tap_gemm(const float *V, const float *u, float *M, int P, int Ci, int Co, int ntaps,
                     void *stream);
 int decnet_tapconv_gather(const float *M, const float *scale, const float *shift, float *y, int B,
