@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256) void deconv2d_k3s3(const float *__restrict__ x
                                                      const float *__restrict__ shift, float *__restrict__ y,
                                                      int Cin, int Cout, int H, int W, int relu) {
     const int Wo = 3 * W, Ho = 3 * H;
-    const int xi = blockIdx.x * 256 + threadIdx.x, yi = blockIdx.y, b = blockIdx.z;
-    if (xi >= W) return;
+    // input pixels of an image numbered row-major across rows: a 324-pixel row does not leave 60 lanes of its sixth wave idle
+    const int pi = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
+    if (pi >= H * W) return;
+    const int yi = pi / W, xi = pi - yi * W;
     const size_t plane = (size_t)H * W;
     const float *xp = x + (size_t)b * Cin * plane + (size_t)yi * W + xi;
     float acc[3][3][CO];
@@ -613,8 +615,8 @@ int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w, const float *sca
                                 float *y, int B, int Cin, int Cout, int H, int W, int relu, void *stream) {
     if (!x || !w || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
-    if (Cout > 8 || 3 * H > 65535 || B > 65535 || 3.0 * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)H, (unsigned)B);
+    if (Cout > 8 || B > 65535 || 9.0 * H * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)ceil_div(H * W, 256), 1u, (unsigned)B);
     hipLaunchKernelGGL((deconv2d_k3s3<8>), grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, Cin,
                        Cout, H, W, relu);
     return decnet_launch_status();
