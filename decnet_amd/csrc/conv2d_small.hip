@@ -20,6 +20,7 @@
 typedef int i32x4_c __attribute__((ext_vector_type(4)));
 typedef float f32x3_u __attribute__((ext_vector_type(3), aligned(4)));   // dword-aligned 12-byte vector (global_store_dwordx3)
 
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 namespace {
 
 // A thread owns 4 consecutive output pixels x CO output channels.  Input taps are bounds-checked
@@ -45,6 +46,8 @@ __global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__rest
                                                     const float *__restrict__ ea, const float *__restrict__ eb) {
     int bx, row;
     if (!decnet_xcd_rows((W + 1023) >> 10, nrows, bx, row)) return;      // rows of one XCD's blocks are neighbours
+    const bool nt = relu & 2;                                            // streaming stores (store_policy)
+    relu &= 1;
     const int x0 = (bx * 256 + threadIdx.x) * 4, b = row / H, yy = row - b * H;
     if (x0 >= W) return;
     const size_t plane = (size_t)H * W;
@@ -118,7 +121,8 @@ __global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__rest
             }
             float *yp = y + ((size_t)b * Cout + co) * plane + (size_t)yy * W + x0;
             if (vec) {
-                *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                if (nt) __builtin_nontemporal_store(f32x4_nt{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4_nt *>(yp));
+                else *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -157,6 +161,8 @@ __global__ __launch_bounds__(256) void conv2d_f32m(Segs in, const float *__restr
     __syncthreads();
     int bx, task;
     if (!decnet_xcd_rows((W + 255) >> 8, ntasks, bx, task)) return;
+    const bool nt = relu & 2;                            // streaming stores (store_policy)
+    relu &= 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = (bx * 4 + wave) * 64;
     if (x0 >= W) return;
@@ -240,7 +246,8 @@ __global__ __launch_bounds__(256) void conv2d_f32m(Segs in, const float *__restr
             }
             float *yp = y + ((size_t)b * Cout + co) * plane + (size_t)row * W + xq;
             if (vec && xq + 3 < W) {
-                *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                if (nt) __builtin_nontemporal_store(f32x4_nt{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4_nt *>(yp));
+                else *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -504,6 +511,14 @@ __global__ __launch_bounds__(256) void dynamic_upsample3(const float *__restrict
         }
 }
 
+// Outputs that the last-level cache cannot keep for their consumer anyway (>= DECNET_NT_MB, default 192 MB against the
+// 256 MB Infinity Cache) leave with nontemporal stores: bit 1 of the kernels' relu argument.  Measured at
+// [16,8,540,972] (268 MB out): 8 -> 8 3 x 3 0.171 -> 0.141 ms, 1 x 1 0.103 -> 0.082.  DECNET_NT_MB=0: every output, < 0: none.
+static int store_policy(double out_bytes) {
+    static const double mb = [] { const char *e = getenv("DECNET_NT_MB"); return e ? atof(e) : 192.0; }();
+    return mb >= 0 && out_bytes >= mb * 1048576.0 ? 2 : 0;
+}
+
 static int conv2d_segs(const Segs &in, const float *w, const float *scale, const float *shift, float *y, int B,
                        int Cout, int H, int W, int k, int dilation, int relu, void *stream, int epi = 0,
                        const float *ea = nullptr, const float *eb = nullptr) {
@@ -520,6 +535,7 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
     if ((double)B * (cin > Cout ? cin : Cout) * H * W >= 9.0e18) return DECNET_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     if (epi && (Cout != 1 || !ea || (epi == 1 && !eb) || epi < 0 || epi > 2)) return DECNET_ERR_UNSUPPORTED;
+    relu = (relu ? 1 : 0) | store_policy(4.0 * B * Cout * H * W);
     // 3 x 3 layers with <= 4 outputs or more than 8 inputs: the fp32 matrix-pipe kernel.  Measured against the packed-FMA
     // kernel at [8,*,540,972] (tools/bench_conv2d_shapes.sh): 16 -> 8 0.149 vs 0.160 ms, 17 -> 8 dilation 3 0.167 vs
     // 0.175, 12 -> 8 0.121 vs 0.129, 8 -> 4 0.045 vs 0.054, 8 -> 3 0.043 vs 0.053; the 8 -> 8 layers (HBM-shaped either

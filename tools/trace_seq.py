@@ -1,5 +1,5 @@
 """The kernels of ONE steady-state forward in launch order with their durations (rocprofv3 kernel trace of
-tools/e2e_profile.py; the span between the last two launches of costvol_cor_ndhwc, rotated so that the forward's
+tools/e2e_profile.py; the span between the last two launches of wino_head_transform, rotated so that the forward's
 first kernel comes first).  python tools/trace_seq.py <dir>"""
 import csv
 import glob
@@ -8,7 +8,7 @@ import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "costvol_cor_ndhwc" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "wino_head_transform" in r["Kernel_Name"]]
 seg = rows[idx[-2]:idx[-1]]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
