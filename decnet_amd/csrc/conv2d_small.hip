@@ -362,7 +362,7 @@ __global__ void pack_weight2d(const float *__restrict__ w, float *__restrict__ w
     wp[i] = v;
 }
 
-__host__ __device__ constexpr int co_pad(int Cout) { return Cout <= 1 ? 1 : Cout <= 4 ? 4 : Cout <= 8 ? 8 : 24; }
+__host__ __device__ constexpr int co_pad(int Cout) { return Cout <= 1 ? 1 : Cout <= 4 ? 4 : Cout <= 8 ? 8 : Cout <= 12 ? 12 : 24; }
 
 // y[b][c][:] = act(y[b][c][:] + shift[c]) in place: the folded-BatchNorm bias and the ReLU of the layers
 // that stay on MIOpen, one pass instead of a bias-add kernel and a clamp kernel.
@@ -546,7 +546,7 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
     const bool want_mfma = force == 2 || (force == 0 && k == 3 && (cop <= 4 || cin > 8));
     if (want_mfma && Cout > 1 && (size_t)cin * k * k * cop * 4 <= 64 * 1024 && H <= 65535) {
         const size_t lds = (size_t)cin * k * k * cop * 4;
-        const int R = cop <= 8 ? 4 : 2;
+        const int R = cop <= 12 ? 4 : 2;
         const int tasks_per_img = ceil_div(H, R * dilation) * dilation;
         const long ntasks = (long)tasks_per_img * B;
         if ((double)ntasks * ceil_div(W, 256) < 2.0e9) {
@@ -556,6 +556,7 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
                        relu, (int)ntasks, tasks_per_img, cin)
             if (cop == 4) { if (k == 3) GOM(1, 3, 4); else GOM(1, 1, 4); }
             else if (cop == 8) { if (k == 3) GOM(2, 3, 4); else GOM(2, 1, 4); }
+            else if (cop == 12) { if (k == 3) GOM(3, 3, 4); else GOM(3, 1, 4); }   // Refinement's 12-channel layers
             else { if (k == 3) GOM(6, 3, 2); else GOM(6, 1, 2); }
 #undef GOM
             return decnet_launch_status();
@@ -564,6 +565,7 @@ static int conv2d_segs(const Segs &in, const float *w, const float *scale, const
     if (Cout <= 1) return launch_conv<1>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s, epi, ea, eb);
     if (Cout <= 4) return launch_conv<4>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
     if (Cout <= 8) return launch_conv<8>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
+    if (Cout <= 12) return launch_conv<12>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);
     return launch_conv<24>(in, w, scale, shift, y, B, Cout, H, W, k, dilation, relu, s);   // co_pad(Cout) = 24
 }
 
@@ -651,6 +653,7 @@ int decnet_conv2d_k3s3_bn_act(const float *x, const float *w, const float *scale
         case 1: GO(1); break;
         case 4: GO(4); break;
         case 8: GO(8); break;
+        case 12: GO(12); break;
         default: GO(24); break;
     }
 #undef GO
