@@ -46,6 +46,7 @@ cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $O/e2e_trace -o e2e -- python3 $R/tools/e2e_profile.py > $O/e2e_trace.log 2>&1
 cd $R
 python3 tools/trace_one_forward.py $O/e2e_trace 60 > $O/${TAG}_e2e_one_forward.txt
+python3 tools/trace_seq.py $O/e2e_trace > $O/${TAG}_e2e_sequence.txt 2>&1
 rm -rf $O/e2e_trace
 ./tools/ubench/softmax_rate.bin > $O/${TAG}_softmax_rate.txt 2>&1
 python3 bench.py > $O/${TAG}_bench.json 2> $O/bench.err
