@@ -210,3 +210,35 @@ def test_hip_vs_reference_live_full_size(dev, B, C, H, W, D, p):
     sc = gscale(rgl.cpu().numpy(), rgr.cpu().numpy())
     assert float((gl - rgl).abs().max()) < 5e-5 * sc
     assert float((gr - rgr).abs().max()) < 5e-5 * sc
+
+
+@pytest.mark.gpu
+def test_long_flat_softmax_is_judged_by_float64(dev):
+    """tools/fuzz_vs_ref.py (40 000 random shapes against oracle/_ref) found ONE family outside the fixed gates above:
+    C = 3, max_disp = 270, dense rows -- 270 nearly equal exponentials per pixel.  The reference sums them in sequence in
+    float32 (SM_kernel.cu:100-122) and is 5.6e-5 px (mean) from the float64 value; this repo's tile-wise sums are 6e-6 px
+    from it, so the two differ by the reference's own rounding.  Gate here: not farther from float64 than the reference."""
+    import torch
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/*.so not built (oracle/ref_build.sh needs /root/reference)")
+    import decnet_amd
+    B, C, H, W, D = 2, 3, 1, 636, 270
+    g = torch.Generator(device="cpu").manual_seed(1670)
+    L, R = (torch.relu(torch.randn(B, C, H, W, generator=g) * 0.5) for _ in range(2))
+    rm = tm = torch.ones(B, H, W)
+    ro, _, rmx = ref.spamat_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
+    o, _, _, m = decnet_amd.spamatvar_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
+    Ld, Rd = L.double().numpy(), R.double().numpy()
+    truth = np.zeros((B, H, W))
+    for b in range(B):
+        for x in range(W):
+            ds = np.arange(0, min(D, x + 1))
+            c = (Ld[b, :, 0, x][:, None] * Rd[b, :, 0][:, x - ds]).sum(0)
+            e = np.exp(c - max(1e-6, c.max()))
+            truth[b, 0, x] = (1e-6 + (e * ds).sum()) / (1e-6 + e.sum())
+    e_ref = np.abs(ro.cpu().numpy() - truth).mean()
+    e_hip = np.abs(o.cpu().numpy() - truth).mean()
+    assert e_hip <= e_ref + 1e-6, (e_hip, e_ref)
+    assert e_ref > 2e-5                       # the premise: the reference itself is not within the 5e-5 mean gate's reach
+    np.testing.assert_allclose(m.cpu().numpy(), rmx.cpu().numpy(), rtol=1e-6, atol=1e-7)
