@@ -19,6 +19,16 @@ from decnet_amd.ext import SpaMat as SM, SpaVar as SV  # noqa: E402
 assert ref.available(), "oracle/_ref/*.so missing"
 
 
+def pack_bits(mk):
+    """float 0/1 mask [B,H,W] -> int64 [B,H,ceil(W/64)], bit i of word w = pixel 64 w + i."""
+    B, H, W = mk.shape
+    wpr = (W + 63) // 64
+    z = torch.zeros(B, H, wpr * 64, dtype=torch.int64, device=mk.device)
+    z[:, :, :W] = (mk != 0).long()
+    sh = torch.arange(64, device=mk.device, dtype=torch.int64)
+    return (z.view(B, H, wpr, 64) << sh).sum(-1).contiguous()
+
+
 def truth_errors(L, Rt, rm, tm, D, ro, o, rmx, m):
     """mean |disparity - float64| and max |max_cost - float64| over the active left pixels, reference and HIP."""
     Ld, Rd = L.double().cpu().numpy(), Rt.double().cpu().numpy()
@@ -87,6 +97,14 @@ for seed in range(first, first + n):
             assert m_hip <= 1.05 * m_ref + 2e-7, "max_cost farther from float64 than the reference: %.3e vs %.3e" % (m_hip, m_ref)
             np.testing.assert_allclose(s.cpu().numpy(), fx["ssum"], rtol=1e-4, atol=1e-9)
         np.testing.assert_allclose(v.cpu().numpy(), rv.cpu().numpy(), rtol=2e-4, atol=2e-3)
+        # the bit-packed mask entry (what the graph's mask kernel feeds): the same four planes, bit for bit
+        try:
+            bo = decnet_amd.spamatvar_forward_bits(L, Rt, pack_bits(rm), pack_bits(tm), D)
+            for a, b_, nm in zip(bo, (o, v, s, m), ("out", "var", "sum", "max")):
+                assert torch.equal(a, b_), "bit-mask entry differs in " + nm
+        except decnet_amd._lib.DecnetHipError as e:
+            if e.code != decnet_amd._lib.UNSUPPORTED:
+                raise
         rgl, rgr = ref.spamat_backward(L, Rt, rm, tm, ro, rs, rmx, go, D)
         gl, gr = torch.empty_like(L), torch.empty_like(Rt)
         assert SM.sparse_matching_cuda_backward(L, Rt, rm, tm, ro, rs, rmx, go, gl, gr, D) == 1
