@@ -1,8 +1,11 @@
 """Build libdecnet_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m decnet_amd.build [--force]
+    python -m decnet_amd.build [--force] [--pybind]
 
 The library lands in decnet_amd/lib/ (git-ignored, but it travels with gpurun snapshots).
+--pybind also builds the two compiled torch modules the reference's autograd Functions import
+(`from ..build.lib import SpaMat`, modules/SparseMatching/functions/SpaMat.py:4; SpaVar likewise) into
+decnet_amd/modules/Sparse{Matching,Var}/build/lib/ -- the place compile.sh:24-28 leaves the reference's own.
 """
 import glob
 import os
@@ -45,6 +48,10 @@ def build(force=False, verbose=False):
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall",
               "-Wno-unused-function"]
     procs, objs = [], []
+    live = {os.path.basename(src) + ".o" for src in sources()}
+    for old in glob.glob(os.path.join(obj_dir, "*.o")):      # objects whose source is gone (pruned experiments)
+        if os.path.basename(old) not in live:
+            os.remove(old)
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
@@ -77,5 +84,57 @@ def build_ubench(force=False):
     return out
 
 
+# ---- the compiled drop-in modules (SURVEY.md 8b "Build boundary") --------------------------------------------
+PYBIND_SRC = os.path.join(CSRC, "pybind")
+PYBIND_MODULES = {          # module name -> (source, directory of the reference layout it lands in)
+    "SpaMat": ("SpaMat_ext.cpp", os.path.join(HERE, "modules", "SparseMatching", "build", "lib")),
+    "SpaVar": ("SpaVar_ext.cpp", os.path.join(HERE, "modules", "SparseVar", "build", "lib")),
+}
+
+
+def pybind_path(name):
+    return os.path.join(PYBIND_MODULES[name][1], name + ".so")
+
+
+def build_pybind(force=False, verbose=False):
+    """SpaMat.so / SpaVar.so: pybind11 modules with the at::Tensor signatures of SM_cuda.cpp:7-33 / SV_cuda.cpp:7-38
+    over the C ABI.  Host-only C++ (g++), linked against libdecnet_hip.so; the library is found through an rpath
+    relative to the module ($ORIGIN) and, for a copy placed into a reference checkout, the absolute build path."""
+    import sysconfig
+    import torch
+    build(force=False)
+    troot = os.path.dirname(torch.__file__)
+    inc = ["-I" + os.path.join(troot, "include"), "-I" + os.path.join(troot, "include", "torch", "csrc", "api", "include"),
+           "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include",
+           "-I" + os.path.join(os.path.dirname(HERE), "include")]
+    defs = ["-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2", "-DTORCH_API_INCLUDE_EXTENSION_H"]
+    cxx = os.environ.get("CXX", "g++")
+    deps = [os.path.join(PYBIND_SRC, "torch_boundary.h"), os.path.join(os.path.dirname(HERE), "include", "decnet_hip.h")]
+    procs, outs = [], []
+    for name, (src, out_dir) in PYBIND_MODULES.items():
+        src = os.path.join(PYBIND_SRC, src)
+        out = pybind_path(name)
+        outs.append(out)
+        if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps + [src]):
+            continue
+        os.makedirs(out_dir, exist_ok=True)
+        cmd = [cxx, "-O2", "-fPIC", "-shared", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-attributes"] + defs + \
+            ["-DTORCH_EXTENSION_NAME=" + name] + inc + [src, "-o", out + ".tmp",
+             "-L" + LIB_DIR, "-ldecnet_hip", "-L" + os.path.join(troot, "lib"), "-lc10", "-ltorch", "-ltorch_cpu",
+             "-ltorch_python", "-lc10_hip", "-ltorch_hip",
+             "-Wl,-rpath,$ORIGIN/../../../../lib", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath," + os.path.join(troot, "lib")]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, out, subprocess.Popen(cmd)))
+    for cmd, out, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        os.replace(out + ".tmp", out)
+    return outs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--pybind" in sys.argv:
+        for p in build_pybind(force="--force" in sys.argv, verbose=True):
+            print(p)

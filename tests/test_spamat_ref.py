@@ -128,11 +128,25 @@ def _t(dev, *arrays):
     return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrays]
 
 
+def providers(kind):
+    """The two bindings of the same C ABI behind the reference's ext-level names: the ctypes shim (decnet_amd.ext) and
+    the COMPILED pybind modules built by `python -m decnet_amd.build --pybind` into the reference's own layout
+    (modules/Sparse*/build/lib/), imported with the reference's own import statement."""
+    if kind == "ctypes_shim":
+        from decnet_amd.ext import SpaMat as SM, SpaVar as SV
+    else:
+        from decnet_amd.modules.SparseMatching.build.lib import SpaMat as SM     # functions/SpaMat.py:4
+        from decnet_amd.modules.SparseVar.build.lib import SpaVar as SV          # functions/SpaVar.py:4
+        assert SM.__file__.endswith(".so") and SV.__file__.endswith(".so")
+    return SM, SV
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("provider", ["ctypes_shim", "compiled_module"])
 @pytest.mark.parametrize("name", K.all_names())
-def test_hip_matches_reference_kernels(dev, name):
+def test_hip_matches_reference_kernels(dev, name, provider):
     import torch
-    from decnet_amd.ext import SpaMat as SM, SpaVar as SV
+    SM, SV = providers(provider)
     fx = fixture(name)
     x = inputs(name, fx)
     D = x["max_disp"]
