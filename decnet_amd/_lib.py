@@ -59,7 +59,7 @@ SIGNATURES = {
     "decnet_tapconv_weight_floats": [_I, _I],
     "decnet_tapconv_pack_weight": [_P, _P] + [_I] * 4 + [_P],
     "decnet_tapconv_split_weight": [_P, _I, _I, _P],
-    "decnet_tap_gemm": [_P, _P, _P] + [_I] * 4 + [_P],
+    "decnet_tap_gemm": [_P, _P, _P] + [_I] * 5 + [_P],
     "decnet_tapconv_gather": [_P, _P, _P, _P] + [_I] * 5 + [_P, _P, _P, _I, _P],
     "decnet_conv3d_cout1_workspace_floats": [_I] * 4,
     "decnet_conv3d_cout1_softargmax_ws": [_P, _P, _F, _F, _P, _P, _P] + [_I] * 5 + [_P],
@@ -78,7 +78,8 @@ class Stage0Params(ctypes.Structure):
                 ("scale_last", _F), ("shift_last", _F)]
 
 
-ERRORS = {-1: "null pointer", -2: "bad shape", -3: "shape not supported by the gfx950 kernels"}
+ERRORS = {-1: "null pointer", -2: "bad shape", -3: "shape not supported by the gfx950 kernels",
+          -4: "non-finite (NaN / Inf) element in a feature map (DECNET_CHECK_FINITE=1)"}
 
 _lib = None
 

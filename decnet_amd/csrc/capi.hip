@@ -38,6 +38,62 @@ static int spamat_pinned() {       // DECNET_SPAMAT_KERNEL, read once
     return pinned;
 }
 
+// ---- DECNET_CHECK_FINITE=1: the NaN contract of include/decnet_hip.h made checkable --------------------------------
+// The reference propagates a NaN / Inf feature into every output whose candidate set touches it (fmaxf / expf,
+// SM_kernel.cu:46-58); the forward kernels here are built with -fno-honor-nans and give an unspecified value there.
+// With the knob set, both feature maps are swept by one reduction kernel before the launch and a non-finite element is
+// an error (DECNET_ERR_NONFINITE, nothing else launched) instead of a silently different result.  The check waits for
+// the stream (one 4-byte read-back), so it is a debugging aid: skipped while the stream is being captured into a graph.
+namespace {
+__global__ __launch_bounds__(256) void count_nonfinite(const float *__restrict__ x, size_t n4, size_t n,
+                                                       unsigned *__restrict__ count) {
+    unsigned bad = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        // exponent all ones <=> Inf or NaN (integer test: immune to -fno-honor-nans style folding)
+        bad += ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) + ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) +
+               ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u) + ((__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))                         // tail
+        bad += (__float_as_uint(x[4 * n4 + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+}  // namespace
+
+static bool check_finite_on() {
+    static const bool on = [] { const char *e = getenv("DECNET_CHECK_FINITE"); return e && atoi(e) != 0; }();
+    return on;
+}
+
+// 0: all finite (or the check is off / the stream is capturing); DECNET_ERR_NONFINITE; positive hipError_t
+static int check_finite(const float *ref, const float *tar, int B, int C, int H, int W, hipStream_t stream) {
+    if (!check_finite_on()) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if ((((uintptr_t)ref) | ((uintptr_t)tar)) & 15) return 0;             // (torch allocations are 512-byte aligned)
+    unsigned *d = nullptr, h = 0;
+    hipError_t e = hipMallocAsync((void **)&d, sizeof(unsigned), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(d, 0, sizeof(unsigned), stream);
+    const size_t n = (size_t)B * C * H * W, n4 = n >> 2;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 + 1 : 2048);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(count_nonfinite, dim3(grid), dim3(256), 0, stream, ref, n4, n, d);
+        hipLaunchKernelGGL(count_nonfinite, dim3(grid), dim3(256), 0, stream, tar, n4, n, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFreeAsync(d, stream);
+    if (e != hipSuccess) return (int)e;
+    return h ? DECNET_ERR_NONFINITE : 0;
+}
+
 // Backward dispatch: matrix-core kernels, row-tile kernels for what they do not cover.
 static int backward_dispatch(int var, const float *ref, const float *tar, const float *rmask,
                              const float *tmask, const float *disparity, const float *out,
@@ -65,6 +121,7 @@ static int forward_dispatch(int mode, const float *ref, const float *tar, const 
                             float *sum_sim, float *max_cost, int B, int C, int H, int W,
                             int max_disp, hipStream_t stream) {
     const int pinned = spamat_pinned();
+    if (int rc = check_finite(ref, tar, B, C, H, W, stream)) return rc;
     if (pinned != 1) {
         int rc = decnet_mfma_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
                                      max_cost, B, C, H, W, max_disp, pinned != 3, 0, stream);
@@ -124,6 +181,7 @@ int decnet_spamatvar_forward_bits(const float *ref, const float *tar, const unsi
     // DECNET_SPAMAT_KERNEL=rowtile pins a kernel this entry does not have -> UNSUPPORTED, the caller falls back to the
     // float-mask entry (decnet_amd.model does)
     if (spamat_pinned() == 1) return DECNET_ERR_UNSUPPORTED;
+    if (int rc2 = check_finite(ref, tar, B, C, H, W, (hipStream_t)stream)) return rc2;
     return decnet_mfma_forward(2, ref, tar, reinterpret_cast<const float *>(ref_bits),
                                reinterpret_cast<const float *>(tar_bits), nullptr, output, variance,
                                sum_similarities, max_cost, B, C, H, W, max_disp, spamat_pinned() != 3, 1,

@@ -1402,14 +1402,16 @@ int decnet_conv3d_wino_gemm(const float *V, const float *u, float *M, int nt, in
 
 /* M[t] = V * U[t] for t < ntaps: ONE V [ceil(Ci/16)][P][16] against ntaps weight matrices
  * u [ntaps][ceil(Ci/16)][224][16] -> M [ntaps][ceil(Co/16)][P][16] (decnet_tapconv_*: dilated convolutions as a
- * per-tap product + gather). */
-int decnet_tap_gemm(const float *V, const float *u, float *M, int P, int Ci, int Co, int ntaps, void *stream) {
+ * per-tap product + gather).  split: the bf16-term copy behind u has been written (decnet_tapconv_split_weight). */
+int decnet_tap_gemm(const float *V, const float *u, float *M, int P, int Ci, int Co, int ntaps, int split, void *stream) {
     if (!V || !u || !M) return DECNET_ERR_NULL_POINTER;
     if (P < 1 || Ci < 1 || Co < 1 || ntaps < 1) return DECNET_ERR_BAD_SHAPE;
     if (Ci % 4 != 0 || Co > W_BN || (double)P * pad16(Ci > Co ? Ci : Co) * 4 * ntaps >= 2147483647.0 ||
         (double)ntaps * pad16(Ci) * W_BN * 4 >= 2147483647.0)
         return DECNET_ERR_UNSUPPORTED;
-    if (gemm_bf16x3() && Ci == 216) {                  // the split copy behind u: decnet_tapconv_split_weight
+    // split != 0 is the caller's statement that decnet_tapconv_split_weight ran after the last pack: without it the
+    // region behind the fp32 matrices is unwritten, so the fp32 kernel is the only correct choice
+    if (split && gemm_bf16x3() && Ci == 216) {         // the split copy behind u: decnet_tapconv_split_weight
         const int *Ub = reinterpret_cast<const int *>(u + (size_t)ntaps * pad16(Ci) * W_BN);
         hipLaunchKernelGGL((wino_gemm_bf16x3<2, 7>), dim3(ceil_div(P, 96), ntaps), dim3(256), 0, (hipStream_t)stream, V, Ub,
                            M, P, Ci, Co, ntaps, 1, 64, 16, 64, 16, 1);

@@ -816,9 +816,18 @@ __global__ __launch_bounds__(64 * ROWW_NW, DECNET_BWD_ROWW_OCC) void spamat_bwd_
                 const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm_own));
                 wt[r] = e * (dm - (float)r);                              // SM_kernel.cu:191
             }
+            // the previous tile's contraction reads of TL / TR (other lanes of this wave) come before these stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<float4 *>(TL + j * TP + 4 * q) = make_float4(wt[0], wt[1], wt[2], wt[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) TR[(4 * q + r) * TP + j] = wt[r];
+            // lane (j, q) wrote, lane (g, e, kh) reads: a hand-off inside the wave.  The LDS executes a wave's accesses in
+            // order, so no instruction is needed -- but the COMPILER must not move the reads above the stores: a
+            // wavefront-scope release / barrier / acquire (they emit nothing) makes that ordering formal
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // left gradient: A = W[right 8kh + s][left 4g + e], B = R[4cg + e][right 8kh + s]
             {
                 const float4 a0 = *reinterpret_cast<const float4 *>(TL + (4 * g4 + e4) * TP + 8 * kh);
@@ -943,7 +952,7 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
             }
         }
     }
-    // dense rows at C <= 8 (SpaMat): both gradients from one pass, one wave per row (DECNET_SPAMAT_BWD=band: the two
+    // dense rows at C <= 8 (SpaMat): both gradients from one pass, four waves per row (DECNET_SPAMAT_BWD=band: the two
     // band launches below, which stay the path of SpaVar and of C > 8)
     static const int band_only = [] { const char *e = getenv("DECNET_SPAMAT_BWD"); return e && !strcmp(e, "band"); }();
     if constexpr (KQ == 2 && !VAR && NT <= 15) {

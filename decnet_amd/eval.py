@@ -101,8 +101,14 @@ def build_model(args, device):
     return model.to(device).eval()
 
 
-def batches_of(dataset, batch_size):
-    """Consecutive batches of equal-shape samples (DataLoader(shuffle=False) order, eval.py:122)."""
+def batches_of(dataset, batch_size, dataset_name=""):
+    """Consecutive batches of equal-shape samples (DataLoader(shuffle=False) order, eval.py:122).
+    MiddleburyMask runs at batch size 1 whatever --batch_size says: every sample carries its own disparity range
+    (eval.py:173-175 takes ``int(n_disp)`` of a one-element tensor) and image size, so a larger batch could only fail
+    in ``batch_max_disp`` / ``collate`` after earlier batches had been computed.  Decided here, before any work."""
+    if dataset_name.lower() == "middleburymask" and batch_size != 1:
+        print("MiddleburyMask: per-sample disparity ranges -> batch size 1 (asked for %d)" % batch_size)
+        batch_size = 1
     idx = list(range(len(dataset)))
     return [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
 
@@ -146,7 +152,7 @@ def test(args, model=None):
         os.makedirs(args.save2where, exist_ok=True)
     if model is None:
         model = build_model(args, device)
-    batches = batches_of(dataset, args.batch_size)
+    batches = batches_of(dataset, args.batch_size, args.dataset)
     lo, hi = shard_range(len(batches), rank, world)
     rec = []                                                            # (batch index, epe, loss_3)
     for bi in range(lo, hi):
@@ -203,7 +209,9 @@ def batch_max_disp(dataset, n_disp, default):
       The reference runs that dataset at batch size 1 (``int()`` of a one-element tensor); a batch whose samples disagree
       is refused here instead of silently taking one of them.
     * 'pairs' (demo.py's directory layout): a calib.txt range rounded up to a multiple of 27, demo.py:149-155.
-    * every other dataset: --max_disp (eval.py never touches it)."""
+    * every other dataset: --max_disp (eval.py never touches it).
+    Ranges above 272 at full resolution (stage-3 bands wider than 18 tiles) leave the matrix-core SpaMat kernels for the
+    row-tile fallback (`spamat_rowtile.hip`): same results, several times slower -- Middlebury at full resolution."""
     ds = dataset.lower()
     nds = sorted({int(v) for v in n_disp})
     if ds == "middleburymask":

@@ -457,7 +457,7 @@ class ASPP(nn.Module):
         with torch.cuda.device(x.device):
             st = _stream(x)
             _lib.check(L.decnet_tapconv_to_chunks(x.data_ptr(), V.data_ptr(), B, Ci, H, W, st), "decnet_tapconv_to_chunks")
-            _lib.check(L.decnet_tap_gemm(V.data_ptr(), pk["u"].data_ptr(), T.data_ptr(), P, Ci, Co, pk["ntaps"], st),
+            _lib.check(L.decnet_tap_gemm(V.data_ptr(), pk["u"].data_ptr(), T.data_ptr(), P, Ci, Co, pk["ntaps"], 1, st),
                        "decnet_tap_gemm")
             _lib.check(L.decnet_tapconv_gather(T.data_ptr(), pk["scale"].data_ptr(), pk["shift"].data_ptr(),
                                                y.data_ptr(), B, Co, H, W, nb, arr(pk["tap0"]), arr(pk["ks"]),

@@ -20,7 +20,10 @@
  *     touches (fmaxf/expf on NaN, SM_kernel.cu:46-58); the SpaMat/SpaVar forward kernels here
  *     are built with -fno-honor-nans (decnet_amd/build.py), so a NaN input gives an unspecified
  *     value at the pixels whose candidate set contains it -- never a fault, never an effect on
- *     other pixels.  Check inputs upstream (torch.isfinite) when that matters.
+ *     other pixels.  DECNET_CHECK_FINITE=1 (environment, read once) makes every SpaMat/SpaVar forward entry
+ *     sweep both feature maps first (one reduction kernel each, then a 4-byte read-back: the call
+ *     waits for the stream) and return DECNET_ERR_NONFINITE with nothing else launched; the check is
+ *     skipped while the stream is being captured into a graph.
  *   - Return value: 0 (DECNET_OK) on success, a negative DECNET_ERR_* for rejected
  *     arguments (nothing is enqueued), or a positive hipError_t from the launch.
  *     (The reference's pybind functions always return 1 and check nothing,
@@ -39,6 +42,7 @@ extern "C" {
 #define DECNET_ERR_NULL_POINTER (-1)
 #define DECNET_ERR_BAD_SHAPE (-2)     /* non-positive dim, max_disp < 1, index space > 2^31 */
 #define DECNET_ERR_UNSUPPORTED (-3)   /* shape does not fit the kernels' LDS tiling */
+#define DECNET_ERR_NONFINITE (-4)     /* DECNET_CHECK_FINITE=1 and a feature map holds a NaN / Inf (nothing launched) */
 
 /* Library / build identification: "decnet_hip <version> gfx950". */
 const char *decnet_version(void);
@@ -324,8 +328,10 @@ int decnet_deconv2d_k3s3_bn_act(const float *x, const float *w_packed, const flo
  * the ASPP block of FeatExtNetChannelPlus (submodule.py:225-241).  All branches share the input:
  *   decnet_tapconv_to_chunks   x [B,Ci,H,W] -> V [ceil(Ci/16)][P=B*H*W][16]
  *   decnet_tapconv_pack_weight one branch's w [Co,Ci,k,k] -> taps tap0.. of u (decnet_tapconv_weight_floats)
- *   decnet_tapconv_split_weight after the last branch: the bf16-term copy of u behind it (read when Ci = 216)
- *   decnet_tap_gemm            T[t] = V * u[t] for every tap t (bf16x3 / fp32 MFMA), T [ntaps][ceil(Co/16)][P][16]
+ *   decnet_tapconv_split_weight after the last branch (optional): the bf16-term copy of u behind it
+ *   decnet_tap_gemm            T[t] = V * u[t] for every tap t, T [ntaps][ceil(Co/16)][P][16].  split = 1 states that
+ *                              decnet_tapconv_split_weight has run on this u since its last pack: the bf16x3 kernel
+ *                              then reads that copy (Ci = 216); split = 0: fp32 MFMA on the packed matrices alone
  *   decnet_tapconv_gather      y[b, br*Co+co, y, x] = act(scale * sum_t T[t][co][p + offset] + shift),
  *                              taps outside the image skipped; y [B, nbranch*Co, H, W]
  * Ci % 4 == 0, Co <= 224, nbranch <= 4.
@@ -336,7 +342,7 @@ size_t decnet_tapconv_weight_floats(int Ci, int ntaps);
 int decnet_tapconv_pack_weight(const float *w, float *u, int Co, int Ci, int k, int tap0, void *stream);
 int decnet_tapconv_split_weight(float *u, int Ci, int ntaps, void *stream);
 int decnet_tap_gemm(const float *V, const float *u, float *M, int P, int Ci, int Co, int ntaps,
-                    void *stream);
+                    int split, void *stream);
 int decnet_tapconv_gather(const float *M, const float *scale, const float *shift, float *y, int B,
                           int Co, int H, int W, int nbranch, const int *tap0, const int *k,
                           const int *dil, int relu, void *stream);

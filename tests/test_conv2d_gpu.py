@@ -1,6 +1,8 @@
 """Parity of the fused small-channel Conv2dUnit / Deconv2dUnit kernels (csrc/conv2d_small.hip) with
 torch CPU conv2d -> batch_norm(eval) -> relu (the third-party arithmetic the reference calls,
 modules/submodule.py:15-87).  -m gpu.  Tolerance: 2e-5 * max|y| (fp32, different summation order)."""
+import os
+
 import pytest
 import torch
 
@@ -274,6 +276,93 @@ def test_aspp_tap_gemm_path(dev, c, rates, shape):
         got = md(x.to(dev)).cpu()
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max()))
+
+
+DIRECT = [  # (segments, Cout, k, dilation, (B, H, W))
+    ((8,), 3, 3, 1, (1, 9, 131)), ((8,), 8, 3, 1, (2, 7, 257)), ((12,), 12, 3, 1, (1, 6, 99)),
+    ((16,), 8, 3, 1, (1, 11, 65)), ((8, 8, 1), 8, 3, 3, (1, 13, 77)), ((3,), 8, 3, 1, (1, 5, 33)),
+    ((8, 4), 24, 3, 2, (1, 9, 51)), ((24,), 24, 1, 1, (1, 4, 45)), ((8,), 4, 1, 1, (1, 3, 1027)),
+    ((5, 4), 12, 3, 1, (2, 5, 19)),
+]
+
+
+@pytest.mark.parametrize("segs,cout,k,dil,shape", DIRECT)
+def test_conv2d_cat_bn_act_c_entry(dev, segs, cout, k, dil, shape):
+    """decnet_conv2d_cat_bn_act itself (ctypes): odd widths, dilation > 1, every output-channel tier (3 / 4, 8, 12, 24),
+    concatenated inputs, against float64.  Which kernel runs is the dispatcher's choice -- the *_forced_kernels test
+    below repeats this with DECNET_CONV2D_SMALL=mfma / valu and nontemporal stores on every output (DECNET_NT_MB=0)."""
+    import ctypes
+    from decnet_amd import _lib
+    L = _lib.lib()
+    B, H, W = shape
+    cin = sum(segs)
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in segs]
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(torch.cat(xs, 1).double(), w.double(), padding=dil * (k // 2), dilation=dil)
+    ref = torch.relu(ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]).float()
+    st = torch.cuda.current_stream().cuda_stream
+    xd = [x.to(dev).contiguous() for x in xs]
+    wp = torch.empty(L.decnet_conv2d_packed_floats(cin, cout, k, 0), device=dev)
+    wd = w.to(dev)
+    _lib.check(L.decnet_conv2d_pack_weight(wd.data_ptr(), wp.data_ptr(), cin, cout, k, 0, st), "pack")
+    y = torch.full((B, cout, H, W), float("nan"), device=dev)
+    ptrs = (ctypes.c_void_p * len(xd))(*[x.data_ptr() for x in xd])
+    cins = (ctypes.c_int * len(segs))(*segs)
+    sd, hd = scale.to(dev), shift.to(dev)
+    _lib.check(L.decnet_conv2d_cat_bn_act(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(cins, ctypes.c_void_p),
+                                          len(segs), wp.data_ptr(), sd.data_ptr(), hd.data_ptr(), y.data_ptr(), B, cout,
+                                          H, W, k, dil, 1, st), "decnet_conv2d_cat_bn_act")
+    torch.cuda.synchronize()
+    assert float((y.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("force", ["mfma", "valu"])
+def test_conv2d_cat_bn_act_forced_kernels(force):
+    """The same cases with each small-channel kernel forced (conv2d_f32m on v_mfma_f32_4x4x1 incl. the 12-channel tier /
+    the packed-FMA kernel) and every output stored nontemporally -- code paths the graph only reaches at its own shapes."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DECNET_CONV2D_SMALL=force, DECNET_NT_MB="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "test_conv2d_cat_bn_act_c_entry or test_conv_unit_vs_torch_cpu"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_tap_gemm_c_entry_points_with_and_without_the_split_copy(dev, split):
+    """The C protocol itself (ctypes, no model.py): pack -> [split] -> tap_gemm -> gather.  split = 0 is the protocol of
+    a caller that never heard of decnet_tapconv_split_weight: the region behind the fp32 matrices stays unwritten (here:
+    poisoned with NaN) and must not be read."""
+    import ctypes
+    from decnet_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    B, Ci, Co, H, W, dil = 1, 216, 216, 20, 36, 4
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=dil, dilation=dil).float()
+    xd, wd = x.to(dev), w.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    u = torch.full((L.decnet_tapconv_weight_floats(Ci, 9),), float("nan"), device=dev)
+    _lib.check(L.decnet_tapconv_pack_weight(wd.data_ptr(), u.data_ptr(), Co, Ci, 3, 0, st), "pack")
+    if split:
+        _lib.check(L.decnet_tapconv_split_weight(u.data_ptr(), Ci, 9, st), "split")
+    P = B * H * W
+    V = torch.empty(L.decnet_tapconv_chunk_floats(B, Ci, H, W), device=dev)
+    T = torch.empty(9 * ((Co + 15) // 16) * 16 * P, device=dev)
+    y = torch.empty(B, Co, H, W, device=dev)
+    one, zero = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
+    arr = lambda v: (ctypes.c_int * len(v))(*v)
+    _lib.check(L.decnet_tapconv_to_chunks(xd.data_ptr(), V.data_ptr(), B, Ci, H, W, st), "chunks")
+    _lib.check(L.decnet_tap_gemm(V.data_ptr(), u.data_ptr(), T.data_ptr(), P, Ci, Co, 9, split, st), "tap_gemm")
+    _lib.check(L.decnet_tapconv_gather(T.data_ptr(), one.data_ptr(), zero.data_ptr(), y.data_ptr(), B, Co, H, W, 1,
+                                       arr([0]), arr([3]), arr([dil]), 0, st), "gather")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert float((y.cpu() - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_unit_falls_back_when_not_covered(dev):

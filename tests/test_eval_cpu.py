@@ -75,6 +75,9 @@ def test_pair_directory_and_batches(tmp_path):
     assert float(s0[2].max()) < 30.001 and float(s0[2].max()) > 1
     b = dev_eval.batches_of(ds, 8)
     assert b == [[0, 1]]
+    # MiddleburyMask: per-sample ranges and sizes -> batch size 1, decided before any batch is computed
+    assert dev_eval.batches_of(ds, 8, "MiddleburyMask") == [[0], [1]]
+    assert dev_eval.batches_of(ds, 8, "kitti15mask") == [[0, 1]]
     cols = dev_eval.collate([s0, s1])
     assert cols[0].shape == (2, 3, 27, 54) and cols[12] == ["p0", "p1"]
 
