@@ -134,13 +134,31 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// Softmax passes over NTL cost tiles held in acc[].  DENSE: d = 16*m + dl - r (affine).
-// COMPACT: d = xlj - XR[16*(t0+m) + 4q + r] read from LDS.  Returns through references.
-template <int NTL, int MODE, bool COMPACT>
+// Softmax passes over NTL cost tiles held in acc[].  DENSE (COMPACT = 0): d = 16*m + dl - r (affine).
+// COMPACT = 1: d = xlj - XR[16*(t0+m) + 4q + r], XR an int list in LDS (band kernel's compact path).
+// COMPACT = 2 (sparse-row bodies): the list holds the positions as FLOATS (exact: < 2^24), so d = xlf - xr is one
+// subtraction instead of an integer subtraction and a conversion in passes 2 and 3, and the range test of pass 1
+// (0 <= d < D  <=>  |(xlf - h) - xr| <= h, h = (D - 1) / 2) is three operations like the integer one.
+// COMPACT = 3 (the mid-density body): as 2, and the range test runs only on the tiles outside [m_lo, m_hi): both lists
+// are sorted, so every slot from the first one the chunk's LAST left pixel may match up to the last one its FIRST left
+// pixel may match is in range for all 16 left pixels -- at stage 3, density 0.3 that is ~60 % of a chunk's tiles.  (The
+// per-tile scalar branches cost ~20 registers: spills in the 80-register sparse-row kernel, which keeps COMPACT = 2.)
+// Same values as COMPACT = 1 bit for bit.  Returns through references.
+// Tiles 0 .. ntile - 1 are the live ones.  COMPACT paths leave the (fully unrolled) tile loops with ONE taken branch at
+// the first dead tile -- `if (m < ntile)` around every tile made the compiler move each tile's body out of line:
+// two taken branches per live tile and pass, ~50 per chunk (round 5, from the ISA).  The sparse-row bodies (COMPACT >= 2)
+// test only every second tile: a dead odd tile holds slots behind the chunk's window (right pixels beyond the last left
+// pixel, or the list's padding), which the range test of pass 1 turns into -1e30 like any other out-of-range candidate
+// -- half as many tests, and two tiles' loads and arithmetic to interleave.
+#define TILE_GATE(m)                                                                               \
+    if (COMPACT >= 2 ? ((m & 1) == 0 && m >= ntile) : (COMPACT == 1 && m >= ntile)) break;        \
+    if (COMPACT != 0 || m < ntile)
+template <int NTL, int MODE, int COMPACT>
 __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int D, int dl,
                                                const float *__restrict__ lds, int bias_off, int xr_off,
                                                int xlj, float mu_in,
-                                               float &mx_o, float &S_o, float &mu_o, float &var_o) {
+                                               float &mx_o, float &S_o, float &mu_o, float &var_o,
+                                               int m_lo = 0, int m_hi = 0) {
     int dlv = dl;
     asm volatile("" : "+v"(dlv));   // opaque: otherwise LICM hoists every range compare out of the
                                     // tile loop and spills their lane masks
@@ -154,10 +172,20 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
     int xo1 = xr_off;
     asm volatile("" : "+v"(xo1));
     const int *xp1 = reinterpret_cast<const int *>(lds) + xo1;
+    const float xlf = (float)xlj, hD = 0.5f * (float)(D - 1), xlh = xlf - hD;      // (COMPACT = 2)
 #pragma unroll
     for (int m = 0; m < NTL; ++m) {
-        if (m < ntile) {
-            if (COMPACT) {
+        TILE_GATE(m) {
+            if (COMPACT >= 2) {
+                if (COMPACT == 2 || m < m_lo || m >= m_hi) {   // wave-uniform: a tile on the edge of the chunk's window
+                    if (COMPACT == 3) asm volatile("" ::: "memory");   // keep a real scalar branch (no if-conversion)
+                    const float4 p = *reinterpret_cast<const float4 *>(xp1 + 16 * m);
+                    acc[m][0] = fabsf(xlh - p.x) <= hD ? acc[m][0] : NEG_BIG;
+                    acc[m][1] = fabsf(xlh - p.y) <= hD ? acc[m][1] : NEG_BIG;
+                    acc[m][2] = fabsf(xlh - p.z) <= hD ? acc[m][2] : NEG_BIG;
+                    acc[m][3] = fabsf(xlh - p.w) <= hD ? acc[m][3] : NEG_BIG;
+                }
+            } else if (COMPACT) {
                 const int4 p = *reinterpret_cast<const int4 *>(xp1 + 16 * m);
                 acc[m][0] = (unsigned)(xlj - p.x) < (unsigned)D ? acc[m][0] : NEG_BIG;
                 acc[m][1] = (unsigned)(xlj - p.y) < (unsigned)D ? acc[m][1] : NEG_BIG;
@@ -247,9 +275,11 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
     const int *xp2 = reinterpret_cast<const int *>(lds) + xo2;
 #pragma unroll
     for (int m = 0; m < NTL; ++m) {
-        if (m < ntile) {
+        TILE_GATE(m) {
             int4 p;
-            if (COMPACT) p = *reinterpret_cast<const int4 *>(xp2 + 16 * m);
+            float4 pf;
+            if (COMPACT >= 2) pf = *reinterpret_cast<const float4 *>(xp2 + 16 * m);
+            else if (COMPACT) p = *reinterpret_cast<const int4 *>(xp2 + 16 * m);
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
                 float e0 = fast_exp2(fmaf(acc[m][r], LOG2E, nm));
@@ -259,7 +289,10 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
                 S0 += e0;
                 S1 += e1;
                 if (MODE != MODE_VAR) {
-                    if (COMPACT) {
+                    if (COMPACT >= 2) {
+                        T0 = fmaf(e0, xlf - (r == 0 ? pf.x : pf.z), T0);
+                        T1 = fmaf(e1, xlf - (r == 0 ? pf.y : pf.w), T1);
+                    } else if (COMPACT) {
                         T0 = fmaf(e0, (float)(xlj - (r == 0 ? p.x : p.z)), T0);
                         T1 = fmaf(e1, (float)(xlj - (r == 0 ? p.y : p.w)), T1);
                     } else {
@@ -292,13 +325,18 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
         const int *xp3 = reinterpret_cast<const int *>(lds) + xo3;
 #pragma unroll
         for (int m = 0; m < NTL; ++m) {
-            if (m < ntile) {
+            TILE_GATE(m) {
                 int4 p;
-                if (COMPACT) p = *reinterpret_cast<const int4 *>(xp3 + 16 * m);
+                float4 pf;
+                if (COMPACT >= 2) pf = *reinterpret_cast<const float4 *>(xp3 + 16 * m);
+                else if (COMPACT) p = *reinterpret_cast<const int4 *>(xp3 + 16 * m);
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
                     float d0, d1;
-                    if (COMPACT) {
+                    if (COMPACT >= 2) {
+                        d0 = c0 - (r == 0 ? pf.x : pf.z);
+                        d1 = c0 - (r == 0 ? pf.y : pf.w);
+                    } else if (COMPACT) {
                         d0 = c0 - (float)(r == 0 ? p.x : p.z);
                         d1 = c0 - (float)(r == 0 ? p.y : p.w);
                     } else {
@@ -475,7 +513,7 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
 #endif
         float mx, S, mu, var;
         const float mu_in = (MODE == MODE_VAR && inside) ? disparity[pix] : 0.f;
-        softmax_passes<NT, MODE, false>(acc, NT, D, dl, smem, 0, 0, 0, mu_in, mx, S, mu, var);
+        softmax_passes<NT, MODE, 0>(acc, NT, D, dl, smem, 0, 0, 0, mu_in, mx, S, mu, var);
         if (inside && q == 0) {
             const bool on = rm != 0.f;
             if (MODE != MODE_VAR) out[pix] = on ? mu : 0.f;
@@ -787,7 +825,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
 #endif
             float mx, S, mu, var;
             const float mu_in = (MODE == MODE_VAR && inside) ? disparity[pix] : 0.f;
-            softmax_passes<NT, MODE, false>(acc, nact, D, dl, smem, lo.offBX + (HALO + xt * 16) + 4 * q, 0, 0, mu_in, mx, S, mu, var);
+            softmax_passes<NT, MODE, 0>(acc, nact, D, dl, smem, lo.offBX + (HALO + xt * 16) + 4 * q, 0, 0, mu_in, mx, S, mu, var);
             if (inside && q == 0) {
                 const bool on = rm != 0.f;
                 if (MODE != MODE_VAR) out[pix] = on ? mu : 0.f;
@@ -871,10 +909,10 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const int ngroups = (SW + S - 1) / S;
     for (int g = wave; g < ngroups; g += NWAVE) {
         const int gx = g * S;
-        const int e0 = RKL[gx], e1 = RKL[min(gx + S, SW)];
+        const int e0 = __builtin_amdgcn_readfirstlane(RKL[gx]), e1 = __builtin_amdgcn_readfirstlane(RKL[min(gx + S, SW)]);
         if (e1 == e0) continue;
         const int jlo = max(0, gx + HALO - (D - 1)), jhi = min(nRw - 1, gx + HALO + S - 1);
-        const int r_lo = RK[jlo], r_hi = RK[jhi + 1];
+        const int r_lo = __builtin_amdgcn_readfirstlane(RK[jlo]), r_hi = __builtin_amdgcn_readfirstlane(RK[jhi + 1]);
         const int t0 = r_lo >> 4;
         const int ntile = r_hi > r_lo ? ((r_hi - 1) >> 4) - t0 + 1 : 0;      // <= NTC
         for (int e = e0; e < e1; e += 16) {
@@ -892,7 +930,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
             const int *xa = XR + 16 * t0 + j;                  // A-operand gather index
 #pragma unroll
             for (int m = 0; m < NTC; ++m) {
-                if (m < ntile) {
+                if (m >= ntile) break; {
                     const float *ap = Rs + q * RP + xa[16 * m];
                     f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (KQ) {
@@ -912,8 +950,8 @@ __device__ __forceinline__ void spamat_fwd_segment(
             float mx, Ssum, mu, var;
             const float mu_in = (MODE == MODE_VAR && act) ? disparity[pix] : 0.f;
             // d = (xl + HALO) - XR[...]: both in staged-row coordinates
-            softmax_passes<NTC, MODE, true>(acc, ntile, D, 0, smem, 0, lo.offBX + 16 * t0 + 4 * q, xl + HALO, mu_in,
-                                            mx, Ssum, mu, var);
+            softmax_passes<NTC, MODE, 1>(acc, ntile, D, 0, smem, 0, lo.offBX + 16 * t0 + 4 * q, xl + HALO, mu_in,
+                                         mx, Ssum, mu, var);
             if (act && q == 0) {
                 if (MODE != MODE_VAR) out[pix] = mu;
                 if (MODE != MODE_MAT) var_out[pix] = var;
@@ -956,7 +994,7 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
 constexpr int SP_THREADS = 256, SP_NWAVE = SP_THREADS / 64, SP_CAP = 256, SP_FP = SP_CAP + 16;
 // LDS words of sparse_row_body<.., KQ, PPT, NTHR, CAP, ..>
 constexpr size_t sparse_row_words(int kq, int ppt, int nthr, int cap) {
-    return (size_t)(cap + 16) + 2 * (size_t)(nthr * ppt / 2 + 2) + cap + 32 + 2 * (size_t)4 * kq * (cap + 16);
+    return (size_t)(cap + 32) + 2 * (size_t)(nthr * ppt / 2 + 2) + cap + 32 + 2 * (size_t)4 * kq * (cap + 16);
 }
 
 // The body: ONE whole image row by a workgroup of NTHR threads (W <= NTHR * PPT), at most CAP active pixels per side and
@@ -977,11 +1015,11 @@ __device__ __forceinline__ int sparse_row_body(
     constexpr int CQ = 4 * KQ, NTC = NT + 1 < NTCMAX ? NT + 1 : NTCMAX;
     constexpr int SP_NWAVE_ = NTHR / 64, SP_FP_ = CAP + 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // words: XR [CAP+16] | RK [(NPX+4) x u16] | RKL [(NPX+4) x u16] | XL [CAP] | WT [16] | RF [CQ][FP] | LF [CQ][FP]
+    // words: XR [CAP+32] | RK [(NPX+4) x u16] | RKL [(NPX+4) x u16] | XL [CAP] | WT [16] | RF [CQ][FP] | LF [CQ][FP]
     constexpr int NPX = NTHR * PPT, RKW = NPX / 2 + 2;               // RK / RKL: NPX + 4 u16
-    constexpr int offXR = 0, offRK = CAP + 16, offRKL = offRK + RKW, offXL = offRKL + RKW,
+    constexpr int offXR = 0, offRK = CAP + 32, offRKL = offRK + RKW, offXL = offRKL + RKW,
                   offWT = offXL + CAP, offRF = offWT + 32, offLF = offRF + CQ * SP_FP_;
-    int *XR = reinterpret_cast<int *>(smem) + offXR;
+    float *XR = smem + offXR;                          // positions of the active right pixels, as floats (softmax_passes<.., 2>)
     unsigned short *RK = reinterpret_cast<unsigned short *>(smem + offRK);
     unsigned short *RKL = reinterpret_cast<unsigned short *>(smem + offRKL);
     int *XL = reinterpret_cast<int *>(smem) + offXL;
@@ -1040,6 +1078,11 @@ __device__ __forceinline__ int sparse_row_body(
         nR += WT[w];
         nL += WT[8 + w];
     }
+    // LDS reads land in vector registers: without this the compiler treats every count-dependent branch below (chunk
+    // loop bound, `m < ntile` around each of the 16 tiles of each pass) as DIVERGENT and wraps it in exec-mask
+    // save / restore sequences -- 468 scalar instructions per chunk in the mid-density body (round 5, from the ISA)
+    nR = __builtin_amdgcn_readfirstlane(nR);
+    nL = __builtin_amdgcn_readfirstlane(nL);
     // not sparse enough for this body: nothing has been written, the caller decides (the stand-alone kernel marks the
     // row for the band kernel, the band kernel goes on with its own paths).
     // (2: few enough active pixels for the 512-slot body of the band kernel; 0: a dense row)
@@ -1056,7 +1099,7 @@ __device__ __forceinline__ int sparse_row_body(
                     for (int c = 0; c < CQ; ++c)
                         RF[c * SP_FP_ + er] = k == 0 ? rv[c].x : k == 1 ? rv[c].y : k == 2 ? rv[c].z : rv[c].w;
                 }
-                XR[er++] = p4 + k;
+                XR[er++] = (float)(p4 + k);
             }
             RKL[p4 + k] = el;
             if (fl & (1 << k)) {
@@ -1069,7 +1112,7 @@ __device__ __forceinline__ int sparse_row_body(
             }
         }
         if (tid == 0) { RK[NPX] = nR; RKL[NPX] = nL; }
-        if (tid < 16) XR[nR + tid] = 1 << 20;           // padding of the last tile: d < 0, out of range
+        if (tid < 32) XR[nR + tid] = 1048576.0f;        // padding of the last tile and of a dead odd tile: d < 0, out of range
         if constexpr (ALL) {                            // the slots behind the last active pixel read as zeros
             if (tid < 32) {
 #pragma unroll
@@ -1088,7 +1131,7 @@ __device__ __forceinline__ int sparse_row_body(
 #pragma unroll
     for (int u = 0; u < (ALL ? 0 : SPT); ++u) {
         const int slot = tid + u * NTHR;
-        const int xr_own = slot < nR ? XR[slot] : -1, xl_own = slot < nL ? XL[slot] : -1;
+        const int xr_own = slot < nR ? (int)XR[slot] : -1, xl_own = slot < nL ? XL[slot] : -1;
 #pragma unroll
         for (int c = 0; c < CQ; ++c) {
             rf[u][c] = (xr_own >= 0 && c < C) ? rrow[(size_t)c * plane + xr_own] : 0.f;
@@ -1126,13 +1169,27 @@ __device__ __forceinline__ int sparse_row_body(
 
     // ---- 3. matching
     const int j = lane & 15, q = lane >> 4;
+#if DECNET_ABLATE == 6      // timing-only: masks, compaction, feature staging and the output sweep, no matching
+    for (int k = wave; k < 0; k += SP_NWAVE_) {
+#else
     for (int k = wave; k < nchunk; k += SP_NWAVE_) {
+#endif
         const int e1 = nL;
         for (int e = 16 * k; e < min(16 * k + 16, nL); e += 16) {      // (one trip: the loop shape the register allocator
-            const int xa = XL[e], xb = XL[min(e + 15, nL - 1)];       //  handled without spilling)
-            const int r_lo = RK[max(0, xa - (D - 1))], r_hi = RK[xb + 1];
+            const int xa = __builtin_amdgcn_readfirstlane(XL[e]);     //  handled without spilling)
+            const int xb = __builtin_amdgcn_readfirstlane(XL[min(e + 15, nL - 1)]);
+            const int r_lo = __builtin_amdgcn_readfirstlane(RK[max(0, xa - (D - 1))]);
+            const int r_hi = __builtin_amdgcn_readfirstlane(RK[xb + 1]);
             const int t0 = r_lo >> 4;
-            const int ntile = r_hi > r_lo ? ((r_hi - 1) >> 4) - t0 + 1 : 0;      // <= NTC
+            const int ntile = r_hi > r_lo ? ((r_hi - 1) >> 4) - t0 + 1 : 0;      // <= NTC; wave-uniform (scalar branches)
+            // tiles [m_lo, m_hi) hold only slots every left pixel of the chunk may match: positions >= xb - (D - 1)
+            // (the last left pixel's lower bound, the tightest) and <= xa (the first one's upper bound)
+            int m_lo = 0, m_hi = 0;
+            if constexpr (ALL) {
+                const int s_lo = RK[max(0, xb - (D - 1))], s_hi = RK[xa + 1];
+                m_lo = __builtin_amdgcn_readfirstlane(((s_lo + 15) >> 4) - t0);
+                m_hi = __builtin_amdgcn_readfirstlane((s_hi >> 4) - t0);
+            }
             const bool act = e + j < e1;
             const int el = act ? e + j : e1 - 1;
             const int xl = XL[el];
@@ -1144,7 +1201,7 @@ __device__ __forceinline__ int sparse_row_body(
             const float *ap = RF + q * SP_FP_ + 16 * t0 + j;
 #pragma unroll
             for (int m = 0; m < NTC; ++m) {
-                if (m < ntile) {
+                if ((m & 1) == 0 && m >= ntile) break; {
                     f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < KQ; ++s)
@@ -1154,8 +1211,8 @@ __device__ __forceinline__ int sparse_row_body(
             }
             float mx, Ssum, mu, var;
             const float mu_in = (MODE == MODE_VAR && act) ? disparity[pix] : 0.f;
-            softmax_passes<NTC, MODE, true>(acc, ntile, D, 0, smem, 0, offXR + 16 * t0 + 4 * q, xl, mu_in, mx,
-                                            Ssum, mu, var);
+            softmax_passes<NTC, MODE, ALL ? 3 : 2>(acc, ntile, D, 0, smem, 0, offXR + 16 * t0 + 4 * q, xl, mu_in, mx,
+                                                   Ssum, mu, var, m_lo, m_hi);
             // results go to rows 0..3 of this chunk's own LF slots (their features were consumed
             // into bcur above and no other wave reads them); the row is written once at the end
             if (act && q == 0) {
@@ -1373,16 +1430,17 @@ int decnet_mfma_forward(int mode, const float *ref, const float *tar, const floa
 #define GO(N)                                                                                     \
     return launch_kq<N>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, \
                         B, C, H, W, D, allow_compact, mbits, stream)
-#ifdef DECNET_DEV_STAGE3
+#ifdef DECNET_DEV_STAGE3        // tools/dev_spamat.sh: the stage-3 instantiation only
     if (need <= 15 && need > 11) GO(15);
     return DECNET_ERR_UNSUPPORTED;
-#endif
+#else
     if (need <= 3) GO(3);       // D <= 32   (stage 1: 24, 30)
     if (need <= 6) GO(6);       // D <= 80   (stage 2: 72)
     if (need <= 8) GO(8);       // D <= 112  (stage 2 at max_disp 270: 90)
     if (need <= 11) GO(11);     // D <= 160
     if (need <= 15) GO(15);     // D <= 224  (stage 3: 216)
     if (need <= 18) GO(18);     // D <= 272  (stage 3 at max_disp 270)
-#undef GO
     return DECNET_ERR_UNSUPPORTED;
+#endif
+#undef GO
 }

@@ -231,15 +231,16 @@ def test_long_flat_softmax_is_judged_by_float64(dev):
     """tools/fuzz_vs_ref.py (40 000 random shapes against oracle/_ref) found ONE family outside the fixed gates above:
     C = 3, max_disp = 270, dense rows -- 270 nearly equal exponentials per pixel.  The reference sums them in sequence in
     float32 (SM_kernel.cu:100-122) and is 5.6e-5 px (mean) from the float64 value; this repo's tile-wise sums are 6e-6 px
-    from it, so the two differ by the reference's own rounding.  Gate here: not farther from float64 than the reference."""
+    from it, so the two differ by the reference's own rounding.  Gate here: not farther from float64 than the reference
+    (how far the reference itself is depends on the inputs: 1e-5 .. 6e-5 px over seeds)."""
     import torch
     from oracle import ref
     if not ref.available():
         pytest.skip("oracle/_ref/*.so not built (oracle/ref_build.sh needs /root/reference)")
     import decnet_amd
     B, C, H, W, D = 2, 3, 1, 636, 270
-    g = torch.Generator(device="cpu").manual_seed(1670)
-    L, R = (torch.relu(torch.randn(B, C, H, W, generator=g) * 0.5) for _ in range(2))
+    rs = np.random.RandomState(1670)                  # numpy: the same stream on every host (torch's CPU randn is not)
+    L, R = (torch.from_numpy(np.maximum(rs.standard_normal((B, C, H, W)) * 0.5, 0).astype(np.float32)) for _ in range(2))
     rm = tm = torch.ones(B, H, W)
     ro, _, rmx = ref.spamat_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
     o, _, _, m = decnet_amd.spamatvar_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
@@ -253,6 +254,7 @@ def test_long_flat_softmax_is_judged_by_float64(dev):
             truth[b, 0, x] = (1e-6 + (e * ds).sum()) / (1e-6 + e.sum())
     e_ref = np.abs(ro.cpu().numpy() - truth).mean()
     e_hip = np.abs(o.cpu().numpy() - truth).mean()
+    print("long flat softmax: mean |ref - f64| = %.3g px, mean |hip - f64| = %.3g px" % (e_ref, e_hip))
     assert e_hip <= e_ref + 1e-6, (e_hip, e_ref)
-    assert e_ref > 2e-5                       # the premise: the reference itself is not within the 5e-5 mean gate's reach
+    assert e_hip < 2e-5                                # and close to float64 in absolute terms
     np.testing.assert_allclose(m.cpu().numpy(), rmx.cpu().numpy(), rtol=1e-6, atol=1e-7)
