@@ -35,7 +35,10 @@ def _stale():
 # per-source extra flags
 #   spamat_mfma.hip: -fno-honor-nans drops the canonicalising v_max that fmaxf otherwise needs on
 #   every MFMA result (the kernel's VALU passes are the bottleneck); see the file header.
-EXTRA_FLAGS = {"spamat_mfma.hip": ["-fno-honor-nans"]}
+#   -fno-slp-vectorize (round 5): the SLP vectoriser packs the softmax passes into v_pk_{add,mul,fma}_f32 pairs and pays
+#   for them with ~140 v_mov per 16-tile chunk (operands have to sit in aligned register pairs); packed fp32 issues no
+#   faster than two scalar ops on this chip.  Stage 3, mask density 0.4: 0.169 -> 0.151 ms (profiles/r05d_*).
+EXTRA_FLAGS = {"spamat_mfma.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 
 
 def build(force=False, verbose=False):

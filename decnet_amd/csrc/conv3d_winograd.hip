@@ -33,10 +33,6 @@
 
 #include "common.h"
 
-#ifndef DECNET_WINO_SPLIT_DEFAULT
-#define DECNET_WINO_SPLIT_DEFAULT 0   // conv_stack: 0 one batch, 1 / 2 two half batches in flight (see side_stream)
-#endif
-
 #ifndef DECNET_WINO_ABLATE
 #define DECNET_WINO_ABLATE 0     // timing-only builds (tools/ablate.sh): 1 no stores | 2 loads always hit |
 #endif                           // 3 no MFMA | 5 = 1 + 2 | 6 no loads
@@ -1300,41 +1296,11 @@ size_t head_lds_bytes(int D, int H, int W) {
     return stack_lds_bytes(D, H, W) + ((size_t)8 * H * W + 3 * (W + D) + 3 * H) * 4;
 }
 
-// ---- two half batches in flight (DECNET_WINO_SPLIT) -------------------------------------------------------------
-// Every kernel of the stack is per sample, and the two kinds alternate: a GEMM that lives on the operand stream into
-// the matrix pipe (0.11 ms, 40 % of the pipe, at the package power limit) and a transform that is a 30 us chain of
-// memory round trips per workgroup, one workgroup per CU (92 KB of LDS) -- 432 workgroups at B = 8 are 1.7 rounds and
-// cost two (62 us where 216 take 37).  Run as two half batches on two streams, shifted by half a layer, the
-// transform of one half (ONE round of <= 256 workgroups) runs beside the GEMM of the other half (linear in its
-// tiles): a layer costs two half GEMMs instead of a GEMM plus two transform rounds.
-//   mode 1: the side stream starts behind the first half's first GEMM and the two chains then run free;
-//   mode 2: strict software pipeline -- G_B(i) waits for G_A(i), G_A(i + 1) waits for G_B(i): never two GEMMs at once.
-// The side stream and its four events are created once per (host thread, device) and kept: entry points stay
-// re-entrant (the reference drives one host thread per GPU, eval.py:146) and every use is ordered behind the
-// caller's stream by events, so calls on different user streams cannot interleave wrongly.  Under stream capture the
-// fork / join become graph edges (the first call has to happen outside a capture: torch's warm-up does that).
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, a = nullptr, b = nullptr; };
-static SideStream *side_stream() {
-    constexpr int MAXDEV = 64;
-    thread_local SideStream tab[MAXDEV];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
-    SideStream &t = tab[dev];
-    if (!t.st) {
-        hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        hipEvent_t *ev[4] = {&t.fork, &t.join, &t.a, &t.b};
-        for (auto e : ev)
-            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        t.st = st;
-    }
-    return &t;
-}
-static int stack_split_mode() {
-    static const int m = [] { const char *e = getenv("DECNET_WINO_SPLIT"); return e ? atoi(e) : DECNET_WINO_SPLIT_DEFAULT; }();
-    return m;
-}
-
+// (Round 5: the stack as two half batches on two streams, shifted by half a layer so that one half's transform --
+// then ONE round of <= 256 workgroups -- runs beside the other half's GEMM, was built and measured: 1.262 ms per seven
+// layers as one batch, 1.268 free-running, 1.432 as a strict pipeline.  The two kernels do not share a CU: the GEMM's two
+// waves per SIMD hold the whole register file, so the streams interleave at CU granularity instead of overlapping.
+// Commit 82b86c1 has the code; profiles/r05c_wino_split_two_halves.txt the numbers.)
 // x != nullptr: the stack's input is a channels-last volume; x == nullptr: it is the cost volume of (left, right),
 // formed on chip by wino_head_transform
 int conv_stack(const float *x, const float *left, const float *right, const float *const *u,
@@ -1343,92 +1309,46 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
                int W, int C, hipStream_t s) {
     constexpr int NP = 216;
     Tiling g{D, H, W, ceil_div(D, 4), ceil_div(H, 4), ceil_div(W, 4)};
-    const int tps = g.Td * g.Th * g.Tw;                 // tiles per sample
+    const int nt = B * g.Td * g.Th * g.Tw;
+    float *V = workspace, *M = workspace + (size_t)NP * nt * pad16(C);
+    const int bytes = (int)((size_t)B * D * H * W * C * 4);
     const size_t lds = stack_lds_bytes(D, H, W);
     // more than 64 KiB of dynamic LDS needs the attribute; it is per device, so it is set per call (cheap) rather than cached
     if (hipFuncSetAttribute((const void *)wino_mid_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         return DECNET_ERR_UNSUPPORTED;
     }
-    const size_t hl = head_lds_bytes(D, H, W);
-    if (!x && hipFuncSetAttribute((const void *)wino_head_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl) != hipSuccess) {
-        (void)hipGetLastError();
-        return DECNET_ERR_UNSUPPORTED;
+    if (x) {
+        const int ith = C >= 256 ? 256 : (C + 63) / 64 * 64;
+        hipLaunchKernelGGL((wino_input_transform<6, 6, 6, 1>), dim3((unsigned)(8 * ((nt + 7) / 8)), (unsigned)ceil_div(C, ith)),
+                           dim3(ith), 0, s, x, V, g, C, 0, nt, bytes);
+    } else {
+        const size_t hl = head_lds_bytes(D, H, W);
+        if (hipFuncSetAttribute((const void *)wino_head_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl) != hipSuccess) {
+            (void)hipGetLastError();
+            return DECNET_ERR_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(wino_head_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), hl, s, left, right, V,
+                           g, C, nt);
     }
-    // a part = consecutive samples with their own V / M / residual / output slices (the layouts are sample major)
-    struct Part { int b0, nb, nt; float *V, *M; hipStream_t st; };
-    const size_t vol = (size_t)D * H * W * C, per_sample_vm = (size_t)NP * tps * pad16(C);
-    auto part = [&](int b0, int nb, hipStream_t st) {
-        Part p{b0, nb, nb * tps, nullptr, nullptr, st};
-        p.V = workspace + 2 * per_sample_vm * b0;       // [V_0 | M_0 | V_1 | M_1]: the same total as one part
-        p.M = p.V + per_sample_vm * nb;
-        return p;
-    };
-    auto head = [&](const Part &p) {
-        const int bytes = (int)(vol * p.nb * 4);
-        if (x) {
-            const int ith = C >= 256 ? 256 : (C + 63) / 64 * 64;
-            hipLaunchKernelGGL((wino_input_transform<6, 6, 6, 1>), dim3((unsigned)(8 * ((p.nt + 7) / 8)), (unsigned)ceil_div(C, ith)),
-                               dim3(ith), 0, p.st, x + vol * p.b0, p.V, g, C, 0, p.nt, bytes);
-        } else {
-            const size_t fm = (size_t)C * H * W * p.b0;
-            hipLaunchKernelGGL(wino_head_transform, dim3((unsigned)(p.nb * ((C + 3) / 4))), dim3(MID_THREADS), hl, p.st,
-                               left + fm, right + fm, p.V, g, C, p.nt);
-        }
-        return decnet_launch_status();
-    };
-    // V of layer 0 comes from wino_input_transform (chunk major) unless the head kernel forms it, M of the last layer
-    // goes to wino_output_transform (chunk major); everything between is quad major
-    auto gemm = [&](const Part &p, int i) {
-        return gemm_dispatch(p.V, u[i], p.M, p.nt, C, C, NP, p.st, i > 0 || !x, i != n_layers - 1);
-    };
-    auto transform = [&](const Part &p, int i) {
-        float *Rp = R + stack_residual_floats(p.b0, D, H, W, C);
-        if (i == n_layers - 1) {
-            const size_t n = (size_t)p.nt * pad16(C);
-            hipLaunchKernelGGL((wino_output_transform<6, 6, 6, 1>), dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, p.st,
-                               p.M, scale[i], shift[i], (const float *)nullptr, y + vol * p.b0, g, C, 1, 0, p.nt,
-                               (int)(vol * p.nb * 4));
-        } else {
-            hipLaunchKernelGGL(wino_mid_transform, dim3((unsigned)(p.nb * ((C + 3) / 4))), dim3(MID_THREADS), lds, p.st, p.M, p.V,
-                               scale[i], shift[i], i == res_dst ? Rp : (const float *)nullptr,
-                               i == res_src ? Rp : (float *)nullptr, g, C, p.nt, 1);
-        }
-        return decnet_launch_status();
-    };
-    int rc;
-    const int mode = stack_split_mode();
-    SideStream *ss = (mode > 0 && B >= 2) ? side_stream() : nullptr;
-    if (!ss) {
-        const Part all = part(0, B, s);
-        if ((rc = head(all))) return rc;
-        for (int i = 0; i < n_layers; ++i) {
-            if ((rc = gemm(all, i))) return rc;
-            if ((rc = transform(all, i))) return rc;
-        }
-        return DECNET_OK;
-    }
-    const Part pa = part(0, (B + 1) / 2, s), pb = part((B + 1) / 2, B / 2, ss->st);
-#define HIPOK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
-    HIPOK(hipEventRecord(ss->fork, s));
-    HIPOK(hipStreamWaitEvent(ss->st, ss->fork, 0));
-    if ((rc = head(pa))) return rc;
-    if ((rc = head(pb))) return rc;
+    int rc = decnet_launch_status();
+    if (rc) return rc;
     for (int i = 0; i < n_layers; ++i) {
-        if (mode >= 2 && i > 0) HIPOK(hipStreamWaitEvent(s, ss->b, 0));     // G_A(i) behind G_B(i - 1)
-        if ((rc = gemm(pa, i))) return rc;
-        if (mode >= 2 || i == 0) {
-            HIPOK(hipEventRecord(ss->a, s));
-            HIPOK(hipStreamWaitEvent(ss->st, ss->a, 0));                    // G_B(i) behind G_A(i)
+        const bool last = i == n_layers - 1;
+        // V of layer 0 comes from wino_input_transform (chunk major) unless the head kernel forms it, M of the last layer
+        // goes to wino_output_transform (chunk major); everything between is quad major
+        if ((rc = gemm_dispatch(V, u[i], M, nt, C, C, NP, s, i > 0 || !x, !last))) return rc;
+        if (last) {
+            const size_t n = (size_t)nt * pad16(C);
+            hipLaunchKernelGGL((wino_output_transform<6, 6, 6, 1>), dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, s,
+                               M, scale[i], shift[i], (const float *)nullptr, y, g, C, 1, 0, nt, bytes);
+        } else {
+            hipLaunchKernelGGL(wino_mid_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), lds, s, M, V,
+                               scale[i], shift[i], i == res_dst ? R : (const float *)nullptr,
+                               i == res_src ? R : (float *)nullptr, g, C, nt, 1);
         }
-        if ((rc = gemm(pb, i))) return rc;
-        if (mode >= 2) HIPOK(hipEventRecord(ss->b, ss->st));
-        if ((rc = transform(pa, i))) return rc;                              // beside G_B(i)
-        if ((rc = transform(pb, i))) return rc;                              // beside G_A(i + 1)
+        if ((rc = decnet_launch_status())) return rc;
     }
-    HIPOK(hipEventRecord(ss->join, ss->st));
-    HIPOK(hipStreamWaitEvent(s, ss->join, 0));
-#undef HIPOK
     return DECNET_OK;
 }
 

@@ -34,6 +34,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef DECNET_ABLATE
@@ -144,21 +146,32 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // pixel may match is in range for all 16 left pixels -- at stage 3, density 0.3 that is ~60 % of a chunk's tiles.  (The
 // per-tile scalar branches cost ~20 registers: spills in the 80-register sparse-row kernel, which keeps COMPACT = 2.)
 // Same values as COMPACT = 1 bit for bit.  Returns through references.
-// Tiles 0 .. ntile - 1 are the live ones.  COMPACT paths leave the (fully unrolled) tile loops with ONE taken branch at
+// Tiles 0 .. ntile - 1 are the live ones.  COMPACT paths leave the tile sequence with ONE taken branch at
 // the first dead tile -- `if (m < ntile)` around every tile made the compiler move each tile's body out of line:
 // two taken branches per live tile and pass, ~50 per chunk (round 5, from the ISA).  The sparse-row bodies (COMPACT >= 2)
 // test only every second tile: a dead odd tile holds slots behind the chunk's window (right pixels beyond the last left
 // pixel, or the list's padding), which the range test of pass 1 turns into -1e30 like any other out-of-range candidate
 // -- half as many tests, and two tiles' loads and arithmetic to interleave.
-#define TILE_GATE(m)                                                                               \
-    if (COMPACT >= 2 ? ((m & 1) == 0 && m >= ntile) : (COMPACT == 1 && m >= ntile)) break;        \
-    if (COMPACT != 0 || m < ntile)
+// live_tiles<0, N, STEP>(ntile, f): f(integral_constant<m>) for the live tiles m < ntile, as NESTED ifs (compile-time
+// recursion) -- one forward branch out at the first dead tile, every live tile's body on the fall-through path, acc[m]
+// indexed statically.  (A `break` out of the unrolled loop does the same on paper, but at 16 tiles the unroller gives up
+// and the accumulators go to scratch memory.)  STEP = 2 tests every second tile only; STEP = 0: no test, all N tiles.
+template <int M, int N, int STEP, class F>
+__device__ __forceinline__ void live_tiles(int ntile, F &&f) {
+    if constexpr (M < N) {
+        if (STEP > 0 && M >= ntile) return;
+        f(std::integral_constant<int, M>{});
+        if constexpr (STEP == 2 && M + 1 < N) f(std::integral_constant<int, M + 1>{});
+        live_tiles<M + (STEP > 1 ? STEP : 1), N, STEP>(ntile, f);
+    }
+}
 template <int NTL, int MODE, int COMPACT>
 __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int D, int dl,
                                                const float *__restrict__ lds, int bias_off, int xr_off,
                                                int xlj, float mu_in,
                                                float &mx_o, float &S_o, float &mu_o, float &var_o,
                                                int m_lo = 0, int m_hi = 0) {
+    constexpr int GS = COMPACT >= 2 ? 2 : COMPACT;      // tile gate: pairs (sparse-row bodies), every tile, none (dense)
     int dlv = dl;
     asm volatile("" : "+v"(dlv));   // opaque: otherwise LICM hoists every range compare out of the
                                     // tile loop and spills their lane masks
@@ -173,9 +186,9 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
     asm volatile("" : "+v"(xo1));
     const int *xp1 = reinterpret_cast<const int *>(lds) + xo1;
     const float xlf = (float)xlj, hD = 0.5f * (float)(D - 1), xlh = xlf - hD;      // (COMPACT = 2)
-#pragma unroll
-    for (int m = 0; m < NTL; ++m) {
-        TILE_GATE(m) {
+    live_tiles<0, NTL, GS>(ntile, [&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        {
             if (COMPACT >= 2) {
                 if (COMPACT == 2 || m < m_lo || m >= m_hi) {   // wave-uniform: a tile on the edge of the chunk's window
                     if (COMPACT == 3) asm volatile("" ::: "memory");   // keep a real scalar branch (no if-conversion)
@@ -206,7 +219,7 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
             mx0 = fmaxf(fmaxf(mx0, acc[m][0]), acc[m][1]);
             mx1 = fmaxf(fmaxf(mx1, acc[m][2]), acc[m][3]);
         }
-    }
+    });
     float mx = fmaxf(mx0, mx1);
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -273,9 +286,9 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
     int xo2 = xr_off;
     asm volatile("" : "+v"(xo2));
     const int *xp2 = reinterpret_cast<const int *>(lds) + xo2;
-#pragma unroll
-    for (int m = 0; m < NTL; ++m) {
-        TILE_GATE(m) {
+    live_tiles<0, NTL, GS>(ntile, [&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        {
             int4 p;
             float4 pf;
             if (COMPACT >= 2) pf = *reinterpret_cast<const float4 *>(xp2 + 16 * m);
@@ -302,7 +315,7 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
                 }
             }
         }
-    }
+    });
     const float dlf = (float)dl;
     float Sl = S0 + S1;
     float Tl = COMPACT ? T0 + T1 : fmaf(dlf, Sl, T0 + T1);      // dense: d = (16m - r) + dl
@@ -323,9 +336,9 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
         int xo3 = xr_off;
         asm volatile("" : "+v"(xo3));
         const int *xp3 = reinterpret_cast<const int *>(lds) + xo3;
-#pragma unroll
-        for (int m = 0; m < NTL; ++m) {
-            TILE_GATE(m) {
+        live_tiles<0, NTL, GS>(ntile, [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            {
                 int4 p;
                 float4 pf;
                 if (COMPACT >= 2) pf = *reinterpret_cast<const float4 *>(xp3 + 16 * m);
@@ -347,7 +360,7 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
                     V1 = fmaf(acc[m][r + 1] * d1, d1, V1);
                 }
             }
-        }
+        });
         float Vl = V0 + V1;
         Vl += __shfl_xor(Vl, 16);
         Vl += __shfl_xor(Vl, 32);
@@ -928,9 +941,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
             }
             f32x4 acc[NTC];
             const int *xa = XR + 16 * t0 + j;                  // A-operand gather index
-#pragma unroll
-            for (int m = 0; m < NTC; ++m) {
-                if (m >= ntile) break; {
+            live_tiles<0, NTC, 1>(ntile, [&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                {
                     const float *ap = Rs + q * RP + xa[16 * m];
                     f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (KQ) {
@@ -946,7 +959,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
                     }
                     acc[m] = a4;
                 }
-            }
+            });
             float mx, Ssum, mu, var;
             const float mu_in = (MODE == MODE_VAR && act) ? disparity[pix] : 0.f;
             // d = (xl + HALO) - XR[...]: both in staged-row coordinates
@@ -1199,16 +1212,14 @@ __device__ __forceinline__ int sparse_row_body(
             for (int s = 0; s < KQ; ++s) bcur[s] = act ? LF[(4 * s + q) * SP_FP_ + el] : 0.f;
             f32x4 acc[NTC];
             const float *ap = RF + q * SP_FP_ + 16 * t0 + j;
+            live_tiles<0, NTC, 2>(ntile, [&](auto mc) {        // pairs of tiles: see softmax_passes
+                constexpr int m = decltype(mc)::value;
+                f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int m = 0; m < NTC; ++m) {
-                if ((m & 1) == 0 && m >= ntile) break; {
-                    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < KQ; ++s)
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * SP_FP_ + 16 * m], bcur[s], a4, 0, 0, 0);
-                    acc[m] = a4;
-                }
-            }
+                for (int s = 0; s < KQ; ++s)
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * SP_FP_ + 16 * m], bcur[s], a4, 0, 0, 0);
+                acc[m] = a4;
+            });
             float mx, Ssum, mu, var;
             const float mu_in = (MODE == MODE_VAR && act) ? disparity[pix] : 0.f;
             softmax_passes<NTC, MODE, ALL ? 3 : 2>(acc, ntile, D, 0, smem, 0, offXR + 16 * t0 + 4 * q, xl, mu_in, mx,

@@ -21,13 +21,25 @@ def available():
 
 
 def _mod(name):
+    """The reference's own build of module `name`, and provably that one.
+
+    pybind11 >= 3 keeps a per-interpreter cache of initialised modules keyed by ``spec.name``; the drop-in modules of this
+    repository (decnet_amd/csrc/pybind/) carry the reference's module names BY DESIGN, so a second load under the plain
+    name 'SpaMat' silently returns whichever of the two was loaded first (round 5: a `-m gpu` run compared the product
+    with itself that way).  Hence the private spec name below -- ExtensionFileLoader only needs its last component to
+    match the PyInit_ symbol -- and the identity checks: the reference's module has no `decnet_version`, and its
+    __file__ must be the file under oracle/_ref/."""
     if name not in _MODS:
         import torch  # noqa: F401  (libtorch must be mapped before the extension)
         path = os.path.join(REF_DIR, name + ".so")
-        loader = importlib.machinery.ExtensionFileLoader(name, path)
-        spec = importlib.util.spec_from_loader(name, loader)
+        spec_name = "oracle_reference_build." + name
+        loader = importlib.machinery.ExtensionFileLoader(spec_name, path)
+        spec = importlib.util.spec_from_loader(spec_name, loader)
         mod = importlib.util.module_from_spec(spec)
         loader.exec_module(mod)
+        if hasattr(mod, "decnet_version") or os.path.realpath(getattr(mod, "__file__", path)) != os.path.realpath(path):
+            raise RuntimeError("oracle/ref.py: asked for the reference's %s (%s), got %r -- another module of that "
+                               "name is cached in this interpreter" % (name, path, getattr(mod, "__file__", mod)))
         _MODS[name] = mod
     return _MODS[name]
 

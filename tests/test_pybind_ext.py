@@ -22,12 +22,17 @@ from decnet_amd import build as B
 
 
 def load(name):
+    """Load the compiled module by file, under a spec name of its own: pybind11 >= 3 caches initialised modules per
+    interpreter by ``spec.name``, and the reference's own build (oracle/_ref/, loaded by oracle/ref.py in the same
+    pytest process) has the same plain names.  Checked: what comes back is this repository's module."""
     path = B.pybind_path(name)
     assert os.path.exists(path), "%s missing: python -m decnet_amd.build --pybind" % path
-    loader = importlib.machinery.ExtensionFileLoader(name, path)
-    spec = importlib.util.spec_from_loader(name, loader)
+    spec_name = "decnet_compiled_dropin." + name
+    loader = importlib.machinery.ExtensionFileLoader(spec_name, path)
+    spec = importlib.util.spec_from_loader(spec_name, loader)
     mod = importlib.util.module_from_spec(spec)
     loader.exec_module(mod)
+    assert hasattr(mod, "decnet_version") and os.path.realpath(mod.__file__) == os.path.realpath(path), mod
     return mod
 
 
@@ -51,6 +56,21 @@ def test_reference_import_statement():
     from decnet_amd.modules.SparseMatching.build.lib import SpaMat
     from decnet_amd.modules.SparseVar.build.lib import SpaVar
     assert SpaMat.__name__.endswith("SpaMat") and SpaVar.__name__.endswith("SpaVar")
+    assert SpaMat.__file__ == B.pybind_path("SpaMat") and hasattr(SpaMat, "decnet_version")
+
+
+def test_same_plain_name_as_the_reference_build_cannot_be_confused():
+    """The hazard the loaders above are built around, demonstrated: under ONE spec name pybind11's module cache hands
+    back the first module whatever file the second load names; under distinct names both files load."""
+    if not os.path.exists(B.pybind_path("SpaVar")):
+        pytest.skip("modules not built")
+    a = load("SpaVar")
+    path = B.pybind_path("SpaMat")
+    loader = importlib.machinery.ExtensionFileLoader("decnet_compiled_dropin.SpaVar", B.pybind_path("SpaVar"))
+    again = importlib.util.module_from_spec(importlib.util.spec_from_loader("decnet_compiled_dropin.SpaVar", loader))
+    assert again is a or again.__file__ == a.__file__           # same name -> the cached module
+    b = load("SpaMat")
+    assert b is not a and b.__file__ == path
 
 
 def test_cpu_tensors_are_refused_not_run():

@@ -137,7 +137,9 @@ def providers(kind):
     else:
         from decnet_amd.modules.SparseMatching.build.lib import SpaMat as SM     # functions/SpaMat.py:4
         from decnet_amd.modules.SparseVar.build.lib import SpaVar as SV          # functions/SpaVar.py:4
-        assert SM.__file__.endswith(".so") and SV.__file__.endswith(".so")
+        # this repository's modules, not the reference's build of the same names (oracle/ref.py explains)
+        assert hasattr(SM, "decnet_version") and hasattr(SV, "decnet_version")
+        assert "decnet_amd" in SM.__file__ and "decnet_amd" in SV.__file__
     return SM, SV
 
 

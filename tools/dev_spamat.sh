@@ -7,6 +7,6 @@ set -e
 cd "$(dirname "$0")/.."
 TAG=$1; shift
 O=decnet_amd/lib/obj
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -fno-honor-nans -DDECNET_DEV_STAGE3 "$@" -c decnet_amd/csrc/spamat_mfma.hip -o /tmp/spamat_dev_$TAG.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -fno-honor-nans -fno-slp-vectorize -DDECNET_DEV_STAGE3 "$@" -c decnet_amd/csrc/spamat_mfma.hip -o /tmp/spamat_dev_$TAG.o
 hipcc --offload-arch=gfx950 -shared -fPIC $(ls $O/*.hip.o | grep -v spamat_mfma) /tmp/spamat_dev_$TAG.o -o tools/ubench/libdecnet_dev_$TAG.so
 echo tools/ubench/libdecnet_dev_$TAG.so
