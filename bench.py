@@ -390,16 +390,22 @@ def alt_gemm_leg():
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
+def e2e_model(dev):
+    """The shipped network (demo.sh hyper-parameters), random init with seed 17; thold 0.5 so that the untrained mask
+    generator produces mixed masks."""
+    from decnet_amd.model import get_model
+    torch.manual_seed(17)
+    return get_model(name="sparsedensenetrefinementmask", max_disp=MAX_DISP, base_channels=8, cost_func="cor",
+                     grad_method="detach", num_stage=4, down_scale=3, step=[-1., 1., 1., 1.],
+                     samp_num=[-1., 12., 10., 6.], sample_spa_size_list=[-1, 3, 5, 7],
+                     down_func_name="bicubic", weights=[1., 1., 1., 1.], if_overmask=False, skip_stage_id=4,
+                     use_detail=True, thold=0.5).to(dev).eval()
+
+
 def e2e_bench(B, dev, iters=5):
     """Whole network forward (random-init weights, demo.sh hyper-parameters, thold 0.5 so that the
     untrained mask generator produces mixed masks) on B synthetic 960x540 pairs padded to 972x540."""
-    from decnet_amd.model import get_model
-    torch.manual_seed(17)
-    model = get_model(name="sparsedensenetrefinementmask", max_disp=MAX_DISP, base_channels=8, cost_func="cor",
-                      grad_method="detach", num_stage=4, down_scale=3, step=[-1., 1., 1., 1.],
-                      samp_num=[-1., 12., 10., 6.], sample_spa_size_list=[-1, 3, 5, 7],
-                      down_func_name="bicubic", weights=[1., 1., 1., 1.], if_overmask=False, skip_stage_id=4,
-                      use_detail=True, thold=0.5).to(dev).eval()
+    model = e2e_model(dev)
     g = torch.Generator(device=dev).manual_seed(17)
     left = torch.randn(B, 3, PAD_H, PAD_W, device=dev, generator=g)
     right = torch.randn(B, 3, PAD_H, PAD_W, device=dev, generator=g)
@@ -439,7 +445,199 @@ def e2e_bench(B, dev, iters=5):
             res["hip_graph"] = {"value": B / dtg, "ms_per_batch": 1e3 * dtg, "replay_equals_eager": ok}
         except Exception as e:                          # capture is an optimisation, never a requirement
             res["hip_graph"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        # algorithmic work of one forward, per kernel family: every Conv2dUnit / Deconv2dUnit launch reports its own
+        # (decnet_amd.model.TALLY); stage 0 and the SpaMat / SpaVar passes in closed form (e2e_kernel_table)
+        from decnet_amd import model as M
+        M.TALLY = []
+        try:
+            model(left, right)
+            torch.cuda.synchronize()
+            agg = {}
+            for t in M.TALLY:
+                a = agg.setdefault(t["family"], {"launches": 0, "flops": 0.0, "bytes": 0.0})
+                a["launches"] += 1
+                a["flops"] += t["flops"]
+                a["bytes"] += t["bytes"]
+            res["unit_work"] = agg
+        finally:
+            M.TALLY = None
     return res
+
+
+# rocprofv3 kernel name -> kernel family of the end-to-end table, first match wins
+E2E_FAMILIES = (
+    ("wino_gemm", "stage 0: Winograd GEMMs (7 x Conv3d 216->216) + the ASPP tap GEMM [bf16x3 on the bf16 matrix pipe]"),
+    ("wino_mid_transform", "stage 0: fused output/input Winograd transforms between the layers"),
+    ("wino_head_transform", "stage 0: cost volume formed on chip + first input transform"),
+    ("wino_", "stage 0: other Winograd transforms"),
+    ("cout1_", "stage 0: Conv3d 216->1 + soft-argmax"),
+    ("spamat_fwd", "cost-volume pass: fused SpaMat + SpaVar, stages 1-3"),
+    ("deconv2d_mfma", "2-D trunk: many-channel transposed convolutions [bf16x3]"),
+    ("conv2d_mfma", "2-D trunk: many-channel 3x3 / 1x1 convolutions [bf16x3 on the bf16 matrix pipe]"),
+    ("conv2d_f32m", "2-D trunk: few-channel 3x3 convolutions [fp32, v_mfma_f32_4x4x1]"),
+    ("conv2d_small", "2-D trunk: few-channel convolutions [fp32 FMA]"),
+    ("conv2d_k3s3", "2-D trunk: stride-3 few-channel convolutions"),
+    ("deconv2d_k3s3", "2-D trunk: stride-3 few-channel transposed convolutions"),
+    ("detail_mask", "mask generator tail (sigmoid > thold, bit-packed masks)"),
+    ("warp_disparity", "Refinement: warp of the right features"),
+    ("miopen", "library convolutions (MIOpen / Tensile)"), ("Cijk", "library convolutions (MIOpen / Tensile)"),
+    ("igemm", "library convolutions (MIOpen / Tensile)"), ("MIOpen", "library convolutions (MIOpen / Tensile)"),
+)
+# Unit kinds (decnet_amd.model._tally) -> the family prefix above
+UNIT_KIND_PREFIX = {"mfma": "conv2d_mfma", "mfma_s3": "conv2d_mfma", "mfma_deconv": "deconv2d_mfma", "conv": "conv2d_small",
+                    "conv_s3": "conv2d_k3s3", "deconv": "deconv2d_k3s3", "library": "miopen"}
+
+
+def e2e_kernel_table(B, unit_work, top=5):
+    """The five largest kernel families of ONE end-to-end forward with their roofline position: a child process under
+    `rocprofv3 --kernel-trace` (the program directly behind `--`) runs tools/e2e_profile.py, the launches between the
+    last two stage-0 head kernels are one steady-state forward; algorithmic flops / bytes per family from the layers'
+    own report (unit_work) or, for stage 0 and the cost-volume pass, in closed form.  frac = the larger
+    of (algorithmic bytes / time) / 8 TB/s and (executed flops / time) / the pipe's dense peak."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="decnet_e2e_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "e2e", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "e2e_profile.py"), str(B)], cwd="/tmp", env=env,
+                           timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        files = glob.glob(tmp + "/**/*kernel_trace.csv", recursive=True)
+        if r.returncode != 0 or not files:
+            return {"error": "rocprofv3 --kernel-trace exited with %d" % r.returncode}
+        rows = sorted(csv.DictReader(open(files[0])), key=lambda x: int(x["Start_Timestamp"]))
+        idx = [i for i, x in enumerate(rows) if "wino_head_transform" in x["Kernel_Name"]] or \
+              [i for i, x in enumerate(rows) if "costvol_cor_ndhwc" in x["Kernel_Name"]]
+        if len(idx) < 2:
+            return {"error": "no two stage-0 head launches in the trace"}
+        seg = rows[idx[-2]:idx[-1]]
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fam = collections.OrderedDict()
+    for x in seg:
+        name = x["Kernel_Name"]
+        key = next((p for p, _ in E2E_FAMILIES if p in name), None)
+        label = dict(E2E_FAMILIES).get(key, name[:70])
+        f = fam.setdefault(key or name[:70], {"kernel": label, "calls": 0, "ms": 0.0, "names": set()})
+        f["calls"] += 1
+        f["ms"] += (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6
+        f["names"].add(name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:48])
+    span = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
+    busy = sum(f["ms"] for f in fam.values())
+    # closed-form algorithmic work of the non-Unit families (both views are one batch of 2 B in the extractor)
+    C0, H0, W0, D0 = STAGES[0]
+    nt = B * ((D0 + 3) // 4) * ((H0 + 3) // 4) * ((W0 + 3) // 4)
+    cp = (C0 + 15) // 16 * 16
+    aspp_flops = 2.0 * (2 * B * H0 * W0) * C0 * C0 * 28          # 1x1 + three dilated 3x3 branches = 28 taps
+    work = {
+        "wino_gemm": {"flops": 7 * 2.0 * 216 * nt * C0 * C0 + aspp_flops, "executed_x": 6.0, "peak_tf": MFMA_BF16_PEAK_TF,
+                      "bytes": 7 * (2.0 * 216 * nt * cp * 4 + 216 * cp * 224 * 6) + aspp_flops / (2.0 * C0) * 4 * 2},
+        "wino_mid_transform": {"bytes": 6 * 2.0 * 216 * nt * cp * 4},
+        "wino_head_transform": {"bytes": 216.0 * nt * cp * 4 + 2.0 * B * C0 * H0 * W0 * 4},
+        "spamat_fwd": {"bytes": sum(4.0 * B * H * W * (2 * C + 2 + 4) for (C, H, W, D) in STAGES[1:])},
+    }
+    for kind, w in (unit_work or {}).items():
+        pre = UNIT_KIND_PREFIX.get(kind)
+        if pre:
+            t = work.setdefault(pre, {"flops": 0.0, "bytes": 0.0})
+            t["flops"] = t.get("flops", 0.0) + w["flops"]
+            t["bytes"] = t.get("bytes", 0.0) + w["bytes"]
+    for pre in ("conv2d_mfma", "deconv2d_mfma"):
+        if pre in work:
+            work[pre].update(executed_x=6.0, peak_tf=MFMA_BF16_PEAK_TF)      # three bf16 terms per operand, six products
+    # the few-channel kernels share their layers' report: conv2d_f32m and conv2d_small are two kernels of the "conv" kind
+    if "conv2d_small" in work and "conv2d_f32m" in fam:
+        both = fam["conv2d_f32m"]["ms"] + fam.get("conv2d_small", {"ms": 0.0})["ms"]
+        share = fam["conv2d_f32m"]["ms"] / both if both else 0.0
+        w = work["conv2d_small"]
+        work["conv2d_f32m"] = {"flops": w["flops"] * share, "bytes": w["bytes"] * share, "peak_tf": MFMA_F32_PEAK_TF,
+                               "split_by_time": True}
+        work["conv2d_small"] = {"flops": w["flops"] * (1 - share), "bytes": w["bytes"] * (1 - share),
+                                "peak_tf": MFMA_F32_PEAK_TF, "split_by_time": True}
+    table = []
+    for key, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:top]:
+        row = {"kernel": f["kernel"], "kernel_names": sorted(f["names"])[:4], "calls": f["calls"], "ms": f["ms"],
+               "share_of_busy": f["ms"] / busy}
+        w = work.get(key)
+        if w:
+            fr = []
+            if w.get("bytes"):
+                row["algorithmic_bytes"] = w["bytes"]
+                row["hbm_frac"] = w["bytes"] / f["ms"] / 1e6 / HBM_PEAK_GBS
+                fr.append(("hbm", row["hbm_frac"]))
+            if w.get("flops"):
+                ex = w["flops"] * w.get("executed_x", 1.0)
+                peak = w.get("peak_tf", MFMA_F32_PEAK_TF)
+                row["algorithmic_flops"] = w["flops"]
+                row["executed_flops"] = ex
+                row["matrix_or_fp32_peak_tflops"] = peak
+                row["compute_frac"] = ex / f["ms"] / 1e9 / peak
+                fr.append(("compute", row["compute_frac"]))
+            if w.get("split_by_time"):
+                row["note"] = "conv2d_small and conv2d_f32m run layers of one kind: their joint algorithmic work is split by time"
+            if fr:
+                row["bound"], row["frac"] = max(fr, key=lambda t: t[1])
+        table.append(row)
+    return {"one_forward": {"kernels": len(seg), "span_ms": span, "busy_ms": busy}, "top_kernels": table,
+            "definition": "one steady-state forward out of a rocprofv3 --kernel-trace child run; frac = max(algorithmic "
+                          "bytes / time / 8 TB/s, executed flops / time / dense peak of the pipe the family runs on)"}
+
+
+def e2e_cpu_baseline(budget_s=30.0):
+    """SURVEY 8d metric (1) on the host: the SAME graph -- decnet_amd.model's modules on CPU tensors (their torch
+    fallbacks: the reference's own Conv2d / BatchNorm / grid_sample / interpolate calls), stage 0 through
+    oracle/stage0.py and SpaMat / SpaVar through the C + OpenMP oracle -- on one synthetic 972x540 pair, all host cores.
+    A reported baseline, like `cpu_baseline`; this leg and no product path touches oracle/."""
+    import oracle
+    from oracle import stage0 as o0
+    from decnet_amd import model as M
+    oracle.build()
+    cores = oracle.num_threads()
+    torch.set_num_threads(cores)
+    model = e2e_model(torch.device("cpu"))
+    params = o0.params_from_module(model.cost_regularizer)
+
+    def spamatvar_cpu(L, R, lm, rm, D, out=None):
+        o, s, mx = oracle.spamat_forward(L, R, lm, rm, D)
+        v, _, _ = oracle.spavar_forward(L, R, lm, rm, o, D)
+        return tuple(torch.from_numpy(a) for a in (o, v, s, mx))
+
+    def stage0_cpu(left, right, max_disp, return_reg=False):
+        pred, reg, _ = o0.stage0_forward(left, right, params, max_disp)
+        return (pred, reg) if return_reg else pred
+
+    saved = M.spamatvar_forward
+    M.spamatvar_forward = spamatvar_cpu
+    model.cost_regularizer.stage0 = stage0_cpu
+    try:
+        g = torch.Generator().manual_seed(17)
+        left = torch.randn(1, 3, PAD_H, PAD_W, generator=g)
+        right = torch.randn(1, 3, PAD_H, PAD_W, generator=g)
+        with torch.no_grad():
+            t0 = time.time()
+            model(left, right)                           # warm-up: thread pools, library load
+            warm = time.time() - t0
+            n, t = 0, 0.0
+            while n < 4 and (n == 0 or warm + t + t / n < budget_s):
+                t0 = time.time()
+                model(left, right)
+                t += time.time() - t0
+                n += 1
+    finally:
+        M.spamatvar_forward = saved
+    return {"value": n / t, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pair(s) %dx%d max_disp %d after 1 warm-up pair (%.1f s): whole graph on torch-CPU + the "
+                      "C/OpenMP SpaMat/SpaVar oracle + oracle/stage0.py, %.2f s per pair" % (n, PAD_W, PAD_H, MAX_DISP, warm, t / n)}
 
 
 def train_leg(dev, B=4, iters=30):
@@ -641,7 +839,7 @@ def main_train(args, B, dev, world, rank):
                 pass
             out = {
                 "metric": "stereo pairs/sec, BASELINE config 5 share (SpaMat forward+backward, stages 1-3, + "
-                          "all-reduce of 52.7 MB of gradients)",
+                          "all-reduce of a SYNTHETIC 52.7 MB gradient buffer: the 2-D trunk's backward is outside the path)",
                 "value": world * B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -703,6 +901,9 @@ def main():
                     help="initialise RCCL (backend nccl) and run the per-step collectives (all-gather of the disparity "
                          "maps; config 5: the bucketed gradient all-reduce) even with ONE rank: the N > 1 code path on a "
                          "one-GPU box.  Adds a 'collective' object with the collective's latency and an equality check")
+    ap.add_argument("--no-e2e-table", action="store_true",
+                    help="skip e2e.roofline: the per-kernel-family table of one forward (a child process under "
+                         "rocprofv3 --kernel-trace)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra 'e2e' object: the whole inference graph (decnet_amd.model: the 2-D "
                          "trunk around the hot path) timed on the same batch, eager and as a HIP-graph replay")
@@ -852,7 +1053,7 @@ def main():
             sparse, by_density = None, []
             if args.mask_density >= 1.0 and not args.no_density_sweep:
                 (Lf, Rf) = hp.feats[3]
-                for dens in (0.3, 0.1, 0.05, 0.02):       # the kernel skips work ~ density^2
+                for dens in (0.5, 0.3, 0.1, 0.05, 0.02):  # the kernel skips work ~ density^2
                     _, m2 = make_inputs(B, dev, dens, seed=4242)
                     t = time_kernel(lambda: hp.decnet.spamatvar_forward(Lf, Rf, m2[3][0], m2[3][1], D3,
                                                                         out=hp.outs[2]), 10)
@@ -930,6 +1131,15 @@ def main():
             # v_mfma_f32_16x16x32_bf16, so the kernel is priced with its EXECUTED flops (6 x the algorithmic ones)
             # against the dense bf16 peak; fp32_equivalent_tflops = algorithmic flops / time (157.3 would be the fp32 peak)
             "roofline": dict(roof_head, **{
+                         # FROZEN in round 5 -- do not re-label between rounds
+                         "definition": "dominant kernel = the launch with the largest share of the timed step (the "
+                                       "Winograd GEMM, 7 launches per step).  hbm = its algorithmic operand bytes per "
+                                       "launch (V in + M out + the weights it reads) / its live-measured launch time / "
+                                       "8000 GB/s; mfma = its EXECUTED flops per launch (6 bf16 products per fp32 "
+                                       "product for the bf16x3 kernel) / time / the dense peak of the pipe it runs on.  "
+                                       "bound / achieved / peak / unit / frac are those of the roof with the LARGER "
+                                       "fraction (the binding one); both sub-objects are always present.  traffic = "
+                                       "PMC-counted bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md)",
                          "traffic": traffic.get(tkey, {}).get("total_bytes"),
                          "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes)", "kernel": kern_name,
                          "ms": conv_ms, "flop_per_launch": gemm_mult * kern_flop, "algorithmic_flop_per_launch": kern_flop,
@@ -968,6 +1178,15 @@ def main():
         if sparse:
             out["roofline_costvol_sparse"] = sparse
             out["roofline_costvol_sparse"]["by_density"] = by_density
+            # the cost-volume pass against the HBM roof at the densities the reviews quote, one map (ALGORITHMIC bytes
+            # of the pass -- whole planes, float masks, SURVEY 8d -- over the measured time, whatever really moved)
+            fad = {"1.0": s3_bytes / s3_ms / 1e6 / HBM_PEAK_GBS}
+            for row in by_density:
+                if row["mask_density"] in (0.5, 0.3, 0.1):
+                    fad["%.1f" % row["mask_density"]] = s3_bytes / row["ms"] / 1e6 / HBM_PEAK_GBS
+            out["roofline_costvol"]["frac_at_density"] = fad
+            out["roofline_costvol"]["ms_at_density"] = dict({"1.0": s3_ms}, **{
+                "%.1f" % r_["mask_density"]: r_["ms"] for r_ in by_density if r_["mask_density"] in (0.5, 0.3, 0.1)})
         if world == 1 and not args.no_train and args.config == 2:
             try:
                 out["train"] = train_leg(dev)
@@ -980,6 +1199,10 @@ def main():
                 # the capture worked: same kernels, no launch gaps), beside `value` = the hot path alone
                 hg = out["e2e"].get("hip_graph", {})
                 out["value_end_to_end"] = max(out["e2e"]["value"], hg.get("value", 0.0))
+                if not args.no_e2e_table:
+                    out["e2e"]["roofline"] = e2e_kernel_table(B, out["e2e"].get("unit_work"))
+                if not args.no_cpu_baseline:
+                    out["e2e"]["cpu_baseline"] = e2e_cpu_baseline()
             except Exception as e:                      # never lose the bench line to the extra leg
                 out["e2e"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not args.no_live_traffic:

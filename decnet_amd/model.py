@@ -25,6 +25,30 @@ from .ops import spamatvar_forward, spamatvar_forward_bits
 from .stage0 import CostRegNetNoDown, Stage0
 
 
+# bench.py's end-to-end accounting: a list that every Unit launch appends (kernel family, algorithmic flops, algorithmic
+# bytes) to while it is set; None (the default) costs one comparison per layer.
+TALLY = None
+
+
+def _tally(unit, kind, x):
+    """Algorithmic work of one Conv2dUnit / Deconv2dUnit launch: flops = 2 * outputs * Cin * taps per output, bytes = the
+    input and output tensors once (fp32); the concatenated inputs count as what they are, never as a copy."""
+    xs = x if isinstance(x, (tuple, list)) else (x,)
+    B, _, H, W = xs[0].shape
+    cin = sum(t.shape[1] for t in xs)
+    c = unit.conv
+    k, st, co = c.kernel_size[0], c.stride[0], c.out_channels
+    if isinstance(c, nn.ConvTranspose2d):
+        Ho, Wo = (H - 1) * st - 2 * c.padding[0] + k, (W - 1) * st - 2 * c.padding[0] + k
+        taps = (k * k) / float(st * st)                  # k 3, stride 3: every output pixel has exactly one tap
+    else:
+        Ho = (H + 2 * c.padding[0] - c.dilation[0] * (k - 1) - 1) // st + 1
+        Wo = (W + 2 * c.padding[1] - c.dilation[1] * (k - 1) - 1) // st + 1
+        taps = k * k
+    TALLY.append({"family": kind, "flops": 2.0 * B * Ho * Wo * cin * co * taps,
+                  "bytes": 4.0 * B * (cin * H * W + co * Ho * Wo)})
+
+
 class Unit(nn.Module):
     """conv / transposed conv -> optional BatchNorm2d -> optional ReLU; attributes ``conv`` and
     ``bn`` as in the reference's Conv2dUnit / Deconv2dUnit (submodule.py:15-87)."""
@@ -237,6 +261,8 @@ class Unit(nn.Module):
     def _forward_hip(self, x, kind, out=None, epi=0, ea=None, eb=None, neg_last=False):
         """out: write into this [B,Cout,H,W] buffer (kind "conv"); epi / ea / eb: decnet_conv2d_cat_epilogue's fused tail
         of a single-output layer; neg_last: see _folded."""
+        if TALLY is not None:
+            _tally(self, kind, x)
         if kind == "mfma":
             return self._forward_mfma(x)
         if kind == "mfma_deconv":
@@ -318,6 +344,8 @@ class Unit(nn.Module):
             except DecnetHipError as e:                 # e.g. LDS budget / grid limits of the matrix-core kernel
                 if e.code != UNSUPPORTED:
                     raise
+        if TALLY is not None:
+            _tally(self, "library", x)
         if isinstance(x, (tuple, list)):
             x = torch.cat(tuple(x), 1)
         if (self.bn is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda and

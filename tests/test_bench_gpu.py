@@ -38,6 +38,14 @@ def test_bench_line_contract():
     assert (r["bound"], r["unit"], r["peak"]) in (("mfma", "TFLOP/s", 157.3), ("mfma", "TFLOP/s", 2500.0),
                                                    ("hbm", "GB/s", 8000.0))
     assert r["frac"] == max(r["mfma"]["frac"], (r["hbm"] or {"frac": 0})["frac"])
+    # the definition is frozen (round 5): the binding roof heads the object, both roofs and the wording travel with it,
+    # and the kernel it names is the one profiles/traffic.json counted (key, time)
+    assert "LARGER" in r["definition"] and "EXECUTED flops" in r["definition"]
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        tj = json.load(f)["wino_gemm"]
+    assert tj["kernel_match"] in r["kernel"]
+    if "rocprof_avg_ms" in tj:                          # the committed rocprofv3 --kernel-trace --stats average
+        assert abs(r["ms"] - tj["rocprof_avg_ms"]) < 0.2 * tj["rocprof_avg_ms"], (r["ms"], tj["rocprof_avg_ms"])
     assert d["dtype"].startswith("f32")
     assert 0.15 < r["mfma"]["frac"] < 1.0 and 0.15 < r["frac"] < 1.0 and "wino_gemm" in r["kernel"]
     assert r["traffic"] is None or r["hbm"] is None or \
@@ -51,6 +59,34 @@ def test_bench_line_contract():
     alt = d["alt_wino_gemm_fp32"]                      # round 2's fp32 MFMA Winograd GEMM, measured in a child process
     assert "error" not in alt, alt
     assert alt["value"] > 0 and alt["wino_gemm_ms"] > 0 and 0 < alt["fp32_mfma_frac"] < 1.0
+
+
+def test_costvol_density_map_and_e2e_objects():
+    """roofline_costvol.frac_at_density {1.0, 0.5, 0.3, 0.1} (algorithmic bytes of the pass / time / 8 TB/s) and, in the
+    e2e object, the per-kernel-family roofline table of one forward + the CPU figure for the same metric."""
+    import shutil
+    d = _run("--no-train", "--no-alt", "--no-valu-floor", "--cpu-budget", "2")
+    cv = d["roofline_costvol"]
+    assert sorted(cv["frac_at_density"]) == ["0.1", "0.3", "0.5", "1.0"]
+    assert all(0 < v < 1.2 for v in cv["frac_at_density"].values())
+    assert cv["frac_at_density"]["0.1"] > cv["frac_at_density"]["0.5"] > cv["frac_at_density"]["1.0"]
+    for k, v in cv["frac_at_density"].items():
+        assert abs(v - cv["bytes_per_launch"] / cv["ms_at_density"][k] / 1e6 / 8000.0) < 1e-9
+    e = d["e2e"]
+    assert "error" not in e, e
+    assert d["value_end_to_end"] >= e["value"] > 0
+    cb = e["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and 0 < cb["value"] < e["value"] and cb["cores"] >= 1
+    assert set(e["unit_work"]) >= {"conv", "mfma"}
+    if shutil.which("rocprofv3"):
+        t = e["roofline"]
+        assert "error" not in t, t
+        assert len(t["top_kernels"]) == 5 and t["one_forward"]["kernels"] > 50
+        ms = [k["ms"] for k in t["top_kernels"]]
+        assert ms == sorted(ms, reverse=True) and sum(ms) <= t["one_forward"]["busy_ms"] * 1.0001
+        with_frac = [k for k in t["top_kernels"] if "frac" in k]
+        assert len(with_frac) >= 4 and all(0 < k["frac"] < 1.0 and k["bound"] in ("hbm", "compute") for k in with_frac)
+        assert any("wino_gemm" in " ".join(k["kernel_names"]) for k in t["top_kernels"])
 
 
 def test_bench_train_leg_full_size():

@@ -1,7 +1,10 @@
 """Aggregate rocprofv3 --pmc counter_collection CSVs into per-kernel per-launch means and write
 profiles/traffic.json (the file bench.py reads for the `traffic` fields).
 
-    python tools/pmc_summary.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <raw.json> <traffic.json>
+    python tools/pmc_summary.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <raw.json> <traffic.json> [kernel_stats.csv]
+
+kernel_stats.csv: the `rocprofv3 --kernel-trace --stats` summary of the same command; its average duration per kernel is
+recorded beside the bytes (`rocprof_avg_ms`) -- tests/test_bench_gpu.py holds bench.py's live-measured time against it.
 
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch (summed over the XCDs' L2s).  FETCH_SIZE is
 doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is taken as is."""
@@ -77,6 +80,17 @@ def main():
         wm = sum(a * n for a, n in w) / sum(n for _, n in w)
         fb, wb = 2.0 * 1024.0 * fm, 1024.0 * wm
         res[key] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "kernel_match": sub}
+    if len(sys.argv) > 5:
+        rows = list(csv.DictReader(open(sys.argv[5])))
+        for key, v in res.items():
+            if key == "_how":
+                continue
+            m = [r for r in rows if v["kernel_match"] in r["Name"]]
+            if m:
+                calls = sum(int(r["Calls"]) for r in m)
+                v["rocprof_avg_ms"] = sum(float(r["TotalDurationNs"]) for r in m) / calls / 1e6
+                v["rocprof_calls"] = calls
+                v["rocprof_avg_ms_source"] = "profiles/" + sys.argv[5].split("/")[-1]
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
         if k != "_how":

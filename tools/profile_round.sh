@@ -16,7 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- $BENCH --
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
 cd $R
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/${TAG}_pmc_traffic_raw.json $O/traffic.json
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/${TAG}_pmc_traffic_raw.json $O/traffic.json $O/${TAG}_bench_kernel_stats.csv
 # the sparse-row forward (spamat_fwd_sparse + marker launch of spamat_fwd_mfma), one density per pass pair
 for d in 0.10 0.05 0.02; do
   cd /tmp
