@@ -593,6 +593,26 @@ def e2e_kernel_table(B, unit_work, top=5):
                           "bytes / time / 8 TB/s, executed flops / time / dense peak of the pipe the family runs on)"}
 
 
+def e2e_acc2_leg():
+    """The end-to-end forward once more in a child process with DECNET_CONV2D_ACC=2 (the bf16x3 trunk kernels with a
+    second accumulator set: error below an fp32 fma chain's; the switch is read once per process): what reference-grade
+    fp32 in the many-channel layers costs."""
+    import subprocess
+    env = dict(os.environ, DECNET_CONV2D_ACC="2")
+    code = ("import sys, json, torch; sys.path.insert(0, %r); import bench; "
+            "r = bench.e2e_bench(%d, torch.device('cuda:0')); r.pop('unit_work', None); print(json.dumps(r))" % (ROOT, DEFAULT_B))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        hg = d.get("hip_graph", {})
+        return {"value": max(d["value"], hg.get("value", 0.0)), "unit": "pairs/s",
+                "ms_per_batch": min(d["ms_per_batch"], hg.get("ms_per_batch", 1e9)),
+                "note": "DECNET_CONV2D_ACC=2: conv2d_mfma with two accumulator sets (csrc/conv2d_mfma_acc2.hip); accuracy "
+                        "gate: tests/test_inputdata_gpu.py::test_two_accumulator_trunk_is_as_close_to_float64_as_the_reference"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def e2e_cpu_baseline(budget_s=30.0):
     """SURVEY 8d metric (1) on the host: the SAME graph -- decnet_amd.model's modules on CPU tensors (their torch
     fallbacks: the reference's own Conv2d / BatchNorm / grid_sample / interpolate calls), stage 0 through
@@ -1201,6 +1221,8 @@ def main():
                 out["value_end_to_end"] = max(out["e2e"]["value"], hg.get("value", 0.0))
                 if not args.no_e2e_table:
                     out["e2e"]["roofline"] = e2e_kernel_table(B, out["e2e"].get("unit_work"))
+                if not args.no_alt and os.environ.get("DECNET_CONV2D_ACC", "") == "":
+                    out["e2e"]["two_accumulator_trunk"] = e2e_acc2_leg()
                 if not args.no_cpu_baseline:
                     out["e2e"]["cpu_baseline"] = e2e_cpu_baseline()
             except Exception as e:                      # never lose the bench line to the extra leg

@@ -549,9 +549,27 @@ int launch_tm(int tm, const Segs &in, const i32x4 *wp, const float *scale, const
 
 }  // namespace
 
+// ---- DECNET_CONV2D_ACC=2: every entry point below forwards to conv2d_mfma_acc2.hip (two accumulator sets) ----------
+extern "C" {
+size_t decnet_conv2d_mfma_packed_bytes_acc2(int Cin, int Cout, int k);
+int decnet_conv2d_mfma_pack_weight_acc2(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream);
+size_t decnet_deconv2d_mfma_packed_bytes_acc2(int Cin, int Cout);
+int decnet_deconv2d_mfma_pack_weight_acc2(const float *w, void *w_packed, int Cin, int Cout, void *stream);
+int decnet_conv2d_mfma_cat_bn_act_acc2(const float *const *xs, const int *cins, int nseg, const void *w_packed,
+                                       const float *scale, const float *shift, float *y, int B, int Cout, int H, int W,
+                                       int k, int dilation, int relu, void *stream);
+int decnet_deconv2d_mfma_k3s3_bn_act_acc2(const float *x, const void *w_packed, const float *scale, const float *shift,
+                                          float *y, int B, int Cin, int Cout, int H, int W, int relu, void *stream);
+}
+static bool acc2_mode() {
+    static const bool on = [] { const char *e = getenv("DECNET_CONV2D_ACC"); return e && atoi(e) == 2; }();
+    return on;
+}
+
 extern "C" {
 
 size_t decnet_conv2d_mfma_packed_bytes(int Cin, int Cout, int k) {
+    if (acc2_mode()) return decnet_conv2d_mfma_packed_bytes_acc2(Cin, Cout, k);
     if (Cin < 1 || Cout < 1 || (k != 1 && k != 3)) return 0;
     const size_t blocks = (size_t)ceil_div(Cin, 16) * (k * k) * 3 + 3;       // + 3: the prefetch runs three blocks ahead
     return blocks * padded_nt(Cout) * 64 * 16;
@@ -572,15 +590,18 @@ static int pack_impl(const float *w, void *w_packed, int Cin, int Cout, int k, i
 }
 
 int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream) {
+    if (acc2_mode()) return decnet_conv2d_mfma_pack_weight_acc2(w, w_packed, Cin, Cout, k, stream);
     return pack_impl(w, w_packed, Cin, Cout, k, 0, stream);
 }
 
 size_t decnet_deconv2d_mfma_packed_bytes(int Cin, int Cout) {
+    if (acc2_mode()) return decnet_deconv2d_mfma_packed_bytes_acc2(Cin, Cout);
     if (Cout < 1 || Cout > 7281) return 0;
     return decnet_conv2d_mfma_packed_bytes(Cin, 9 * Cout, 1);
 }
 
 int decnet_deconv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, void *stream) {
+    if (acc2_mode()) return decnet_deconv2d_mfma_pack_weight_acc2(w, w_packed, Cin, Cout, stream);
     if (Cout < 1 || Cout > 7281) return DECNET_ERR_UNSUPPORTED;
     return pack_impl(w, w_packed, Cin, 9 * Cout, 1, 1, stream);
 }
@@ -617,6 +638,9 @@ static int run_impl(const Segs &in, long Cin, const void *w_packed, const float 
 int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int nseg, const void *w_packed,
                                   const float *scale, const float *shift, float *y, int B, int Cout, int H, int W,
                                   int k, int dilation, int relu, void *stream) {
+    if (acc2_mode())
+        return decnet_conv2d_mfma_cat_bn_act_acc2(xs, cins, nseg, w_packed, scale, shift, y, B, Cout, H, W, k, dilation, relu,
+                                                  stream);
     if (!xs || !cins || !w_packed || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (nseg < 1 || nseg > MAXSEG || (k != 1 && k != 3)) return DECNET_ERR_UNSUPPORTED;
     if (B < 1 || Cout < 1 || H < 1 || W < 1 || dilation < 1) return DECNET_ERR_BAD_SHAPE;
@@ -635,6 +659,8 @@ int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int n
 
 int decnet_deconv2d_mfma_k3s3_bn_act(const float *x, const void *w_packed, const float *scale, const float *shift,
                                      float *y, int B, int Cin, int Cout, int H, int W, int relu, void *stream) {
+    if (acc2_mode())
+        return decnet_deconv2d_mfma_k3s3_bn_act_acc2(x, w_packed, scale, shift, y, B, Cin, Cout, H, W, relu, stream);
     if (!x || !w_packed || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;
     if (Cout > 7281) return DECNET_ERR_UNSUPPORTED;

@@ -1,3 +1,9 @@
+// decnet_amd/csrc/conv2d_mfma_acc2.hip -- conv2d_mfma.hip with TWO accumulator sets: the accuracy option of the bf16x3
+// 2-D trunk (DECNET_CONV2D_ACC=2, read once per process by conv2d_mfma.hip, which forwards its entry points to the
+// *_acc2 functions here; the packed weight format differs, so the switch covers packing and launching alike).
+// Round 4 measured it (tools/experiments then): error against float64 0.58 x the one-accumulator kernel's, i.e. below an
+// fp32 fma chain's, for 20 - 50 % of the layer time.  Round 5 ships it as the supported way to reference-grade fp32 in the
+// many-channel layers (the alternative was DECNET_CONV2D_MFMA=0: the library's kernels).
 // decnet_amd/csrc/conv2d_mfma.hip -- the many-channel Conv2dUnit layers of the 2-D trunk on the matrix cores.
 //
 // Replaces (eval mode) the library convolution behind
@@ -590,7 +596,7 @@ int launch_tm(int tm, const Segs &in, const i32x4 *wp, const float *scale, const
 
 extern "C" {
 
-size_t decnet_conv2d_mfma_packed_bytes(int Cin, int Cout, int k) {
+size_t decnet_conv2d_mfma_packed_bytes_acc2(int Cin, int Cout, int k) {
     if (Cin < 1 || Cout < 1 || (k != 1 && k != 3)) return 0;
     const size_t blocks = (size_t)ceil_div(Cin, 16) * (k * k) * 2 + 2;       // + 2: the prefetch runs one (chunk, tap) ahead
     return blocks * padded_nt(Cout) * 64 * 16;
@@ -598,7 +604,7 @@ size_t decnet_conv2d_mfma_packed_bytes(int Cin, int Cout, int k) {
 
 static int pack_impl(const float *w, void *w_packed, int Cin, int Cout, int k, int tr, void *stream) {
     if (!w || !w_packed) return DECNET_ERR_NULL_POINTER;
-    const size_t bytes = decnet_conv2d_mfma_packed_bytes(Cin, Cout, k);
+    const size_t bytes = decnet_conv2d_mfma_packed_bytes_acc2(Cin, Cout, k);
     if (!bytes) return DECNET_ERR_UNSUPPORTED;
     const int NT = padded_nt(Cout);
     const int nchunk = ceil_div(Cin, 16);
@@ -611,16 +617,16 @@ static int pack_impl(const float *w, void *w_packed, int Cin, int Cout, int k, i
     return decnet_launch_status();
 }
 
-int decnet_conv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream) {
+int decnet_conv2d_mfma_pack_weight_acc2(const float *w, void *w_packed, int Cin, int Cout, int k, void *stream) {
     return pack_impl(w, w_packed, Cin, Cout, k, 0, stream);
 }
 
-size_t decnet_deconv2d_mfma_packed_bytes(int Cin, int Cout) {
+size_t decnet_deconv2d_mfma_packed_bytes_acc2(int Cin, int Cout) {
     if (Cout < 1 || Cout > 7281) return 0;
-    return decnet_conv2d_mfma_packed_bytes(Cin, 9 * Cout, 1);
+    return decnet_conv2d_mfma_packed_bytes_acc2(Cin, 9 * Cout, 1);
 }
 
-int decnet_deconv2d_mfma_pack_weight(const float *w, void *w_packed, int Cin, int Cout, void *stream) {
+int decnet_deconv2d_mfma_pack_weight_acc2(const float *w, void *w_packed, int Cin, int Cout, void *stream) {
     if (Cout < 1 || Cout > 7281) return DECNET_ERR_UNSUPPORTED;
     return pack_impl(w, w_packed, Cin, 9 * Cout, 1, 1, stream);
 }
@@ -656,7 +662,7 @@ static int run_impl(const Segs &in, long Cin, const void *w_packed, const float 
     return DECNET_ERR_UNSUPPORTED;
 }
 
-int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int nseg, const void *w_packed,
+int decnet_conv2d_mfma_cat_bn_act_acc2(const float *const *xs, const int *cins, int nseg, const void *w_packed,
                                   const float *scale, const float *shift, float *y, int B, int Cout, int H, int W,
                                   int k, int dilation, int relu, void *stream) {
     if (!xs || !cins || !w_packed || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
@@ -675,7 +681,7 @@ int decnet_conv2d_mfma_cat_bn_act(const float *const *xs, const int *cins, int n
     return run_impl(in, Cin, w_packed, scale, shift, y, B, Cout, H, W, k, dilation, relu, 0, stream);
 }
 
-int decnet_deconv2d_mfma_k3s3_bn_act(const float *x, const void *w_packed, const float *scale, const float *shift,
+int decnet_deconv2d_mfma_k3s3_bn_act_acc2(const float *x, const void *w_packed, const float *scale, const float *shift,
                                      float *y, int B, int Cin, int Cout, int H, int W, int relu, void *stream) {
     if (!x || !w_packed || !scale || !shift || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return DECNET_ERR_BAD_SHAPE;

@@ -331,6 +331,17 @@ def test_conv2d_cat_bn_act_forced_kernels(force):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_mfma_conv_suite_with_two_accumulator_sets():
+    """DECNET_CONV2D_ACC=2 (csrc/conv2d_mfma_acc2.hip: its own packed-weight format and kernels behind the same entry
+    points; read once per process): every matrix-core convolution case of this file again."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DECNET_CONV2D_ACC="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "mfma and not two_accumulator"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("split", [0, 1])
 def test_tap_gemm_c_entry_points_with_and_without_the_split_copy(dev, split):
     """The C protocol itself (ctypes, no model.py): pack -> [split] -> tap_gemm -> gather.  split = 0 is the protocol of

@@ -195,3 +195,16 @@ def test_fp32_trunk_is_as_close_to_float64_as_the_reference():
                         "pair_matches and (Sceneflow-0006-fill or KITTI-000009_10-fill or real-00004-init17)"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_two_accumulator_trunk_is_as_close_to_float64_as_the_reference():
+    """Third leg (round 5): DECNET_CONV2D_ACC=2 keeps the many-channel 2-D convolutions on the bf16 matrix pipe but
+    collects the small bf16x3 term groups in a second accumulator set (csrc/conv2d_mfma_acc2.hip) -- the supported switch
+    for reference-grade fp32 in the trunk.  Same bound as the library leg: ratio <= 1.1 on the same three pairs."""
+    import subprocess
+    env = dict(os.environ, DECNET_CONV2D_ACC="2", DECNET_TEST_RATIO_BOUND="1.1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-s", "-k",
+                        "pair_matches and (Sceneflow-0006-fill or KITTI-000009_10-fill or real-00004-init17)"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    print("\n".join(ln for ln in r.stdout.splitlines() if "distance to the float64 run" in ln))
