@@ -631,7 +631,10 @@ __device__ __forceinline__ void spamat_fwd_segment(
             const int x = xs + wave * 16 + jl;
             const bool ok = wave < XT && x < W;
 #pragma unroll
-            for (int s = 0; s < KQ; ++s) bfirst[s] = (ok && 4 * s + ql < C) ? lrow[(size_t)(4 * s + ql) * plane + x] : 0.f;
+            for (int s = 0; s < KQ; ++s) {
+                const float v = lrow[(size_t)min(4 * s + ql, C - 1) * plane + min(x, W - 1)];
+                bfirst[s] = (ok && 4 * s + ql < C) ? v : 0.f;
+            }
         }
     }
 
@@ -751,13 +754,18 @@ __device__ __forceinline__ void spamat_fwd_segment(
         const int dl = j - 4 * q;                       // d = 16*m + dl - r
         float bv[KQ <= 6 ? KB : 1], bcur[KB];
         float rm = 0.f;
+        // (unconditional loads from clamped addresses + a select: a load under `ok ? .. : 0` is an exec-mask branch per
+        // channel step -- 16 save / restore sequences per wave-tile at C = 24, round 5 from the ISA)
         auto fetch_left = [&](int xt, float (&dst)[KB]) {
             const int x = xs + xt * 16 + j;
             const bool ok = xt < XT && x < W;
+            const int xc = min(x, W - 1);
             if (KQ) {
 #pragma unroll
-                for (int s = 0; s < KQ; ++s)
-                    dst[s] = (ok && 4 * s + q < C) ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
+                for (int s = 0; s < KQ; ++s) {
+                    const float v = lrow[(size_t)min(4 * s + q, C - 1) * plane + xc];
+                    dst[s] = (ok && 4 * s + q < C) ? v : 0.f;
+                }
             }
         };
         constexpr bool PREF = KQ <= 6;                  // next tile's left operand in flight (C = 72: no room, and
@@ -810,7 +818,8 @@ __device__ __forceinline__ void spamat_fwd_segment(
 #else
                     // accumulate on top of the right-mask bias (0 / -1e30 per right pixel = tile row):
                     // 0 + x is exact and -1e30 + x == -1e30, so this equals adding the bias afterwards
-                    asm volatile("" ::: "memory");      // keep the 15 bias reads from being hoisted together (spills)
+                    if (NT > 8) asm volatile("" ::: "memory");   // keep the 15 bias reads from being hoisted together
+                                                                 // (spills); short bands: let the LDS reads run ahead
                     const float4 bz = *reinterpret_cast<const float4 *>(BX + (HALO + xt * 16) + 4 * q - 16 * m);
                     a4 = f32x4{bz.x, bz.y, bz.z, bz.w};
                     if (KQ) {
