@@ -108,7 +108,7 @@ struct Layout {
     int SW, HALO, RP, Cq;
     int offR, offBX, offRK, offLM, offXL, offWT, total;
 };
-__host__ __device__ inline Layout make_layout(int C, int NT, int XT, int d16 = 0) {
+__host__ __device__ inline Layout make_layout(int C, int NT, int XT, bool d16 = false) {
     Layout l;
     l.SW = XT * 16;
     l.HALO = (NT - 1) * 16;
@@ -117,8 +117,7 @@ __host__ __device__ inline Layout make_layout(int C, int NT, int XT, int d16 = 0
     l.offR = 0;
     // (D16: the same region holds both views as bf16 terms, dense16_body)
     const int swh = ((XT + 1) / 2) * 16;                             // dense16_body runs on half a segment at a time
-    // (d16 = 2, dense_cb_body: the right view only, whole segment)
-    const int rt = d16 == 1 ? 3 * ((C + 7) / 8) * (l.HALO + 2 * swh) * 4 : d16 == 2 ? 3 * ((C + 7) / 8) * (l.HALO + l.SW) * 4 : 0;
+    const int rt = d16 ? 3 * ((C + 7) / 8) * (l.HALO + 2 * swh) * 4 : 0;
     l.offBX = l.offR + (l.Cq * l.RP > rt ? l.Cq * l.RP : rt);
     l.offRK = l.offBX + l.RP;
     l.offLM = l.offRK + l.RP + 4;
@@ -539,153 +538,8 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
 
 }
 
-// ---------------------------------------------------------------------------------------------
-// Dense rows at C = 9 .. 96 on the bf16 matrix cores, "channel block" scheme (round 5; stages 2 and 1: C = 24, 72).
-//
-// Ablation builds of the fp32 band path (tools/r05g.sh): without its v_mfma_f32_16x16x4_f32 stage 2 takes 0.038 instead
-// of 0.060 ms and stage 1 0.0084 instead of 0.0176 -- the fp32 MFMAs hold the FP32 lanes the softmax passes need for
-// 38 % / 52 % of the pass.  dense16_body's remedy (three bf16 terms per operand, products on v_mfma_f32_16x16x32_bf16)
-// puts the four term pairs of 8 channels into the K axis; with more channels that costs a split of EVERY lane's
-// operand per 8 channels and a per-lane choice of terms.  Here the K axis of an MFMA is 32 CHANNELS of one term pair:
-// k group q (= lane >> 4) holds channels 8 (4 b + q) .. + 7 of channel block b, so
-//   * a lane loads and splits only ITS 8 channels of the left pixel (one split3x8 per block, no selects, no duplicated
-//     loads across the four k groups),
-//   * the right view is split once per workgroup while it is staged, RT [term][C / 8][position][8 ch x bf16] as in
-//     dense16_body, and an A operand is one ds_read_b128 of (term, group 4 b + q),
-//   * a tile takes the eight term pairs above 2^-32 (hh hm mh mm hl lh ml lm) = eight MFMAs per block of 32 channels;
-//     C = 24 pads its fourth k group with zeros.
-// The left features never pass through LDS (each is used by exactly one wave-tile): 62 - 69 KB per workgroup, two per CU.
-template <int NT, int MODE, int NBLK>
-__device__ __forceinline__ void dense_cb_body(int *RT, const float *BX, const float *LM, const float *smem,
-                                              const float *__restrict__ lrow, const float *__restrict__ rrow,
-                                              const float *__restrict__ disparity, float *__restrict__ out,
-                                              float *__restrict__ var_out, float *__restrict__ sum_sim,
-                                              float *__restrict__ max_cost, size_t plane, size_t rowpix, int C, int W,
-                                              int D, int xs, int XT, int SW, int HALO, int nRw) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int CG = (C + 7) >> 3;
-    const int j = lane & 15, q = lane >> 4;
-    // ---- this wave's first tile: the left operand of every block, requested before the staging (one round trip)
-    auto load_left = [&](int xt, int b, float (&lv)[8]) {
-        const int g = 4 * b + q, x = xs + xt * 16 + j;
-        const bool ok = xt < XT && x < W && g < CG;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) lv[c] = (ok && 8 * g + c < C) ? lrow[(size_t)(8 * g + c) * plane + x] : 0.f;
-    };
-    float lnext[8];                                                      // one (tile, block) ahead of the MFMAs
-    load_left(wave, 0, lnext);
-    // ---- right view: 8 channels x 4 positions per item, split into the three bf16 terms
-    {
-        const bool al = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
-        const int nq = nRw >> 2, n_items = CG * nq;
-        const int tstride = CG * nRw * 4;                                 // words between terms
-#pragma unroll 1
-        for (int it = tid; it < n_items; it += THREADS) {
-            const int g = it / nq, jq = it - g * nq;
-            const int x = xs - HALO + 4 * jq;
-            float4 v[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                v[c] = 8 * g + c < C ? load4(rrow + (size_t)(8 * g + c) * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
-            int *dst = RT + (g * nRw + 4 * jq) * 4;
-#pragma unroll
-            for (int pz = 0; pz < 4; ++pz) {
-                float xv[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) xv[c] = pz == 0 ? v[c].x : pz == 1 ? v[c].y : pz == 2 ? v[c].z : v[c].w;
-                i32x4 th, tm, tl;
-                split3x8(xv, th, tm, tl);
-                *reinterpret_cast<i32x4 *>(dst + pz * 4) = th;
-                *reinterpret_cast<i32x4 *>(dst + tstride + pz * 4) = tm;
-                *reinterpret_cast<i32x4 *>(dst + 2 * tstride + pz * 4) = tl;
-            }
-        }
-    }
-    __syncthreads();
-
-    const int dl = j - 4 * q;                                            // d = 16 m + dl - r
-    const int tstride = CG * nRw * 4;
-    auto mf = [](const i32x4 &a, const i32x4 &b, const f32x4 &c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    };
-    for (int xt = wave; xt < XT; xt += NWAVE) {
-        const int x0 = xs + xt * 16;
-        if (x0 >= W) break;
-        const int x = x0 + j;
-        const size_t pix = rowpix + x;
-        const bool inside = x < W;
-        const float rm = LM[xt * 16 + j];
-        if (__ballot(rm != 0.f) == 0ull) {                               // no active left pixel in this tile
-            if (inside && q == 0) {
-                if (MODE != MODE_VAR) out[pix] = 0.f;
-                if (MODE != MODE_MAT) var_out[pix] = 0.f;
-                sum_sim[pix] = 0.f;
-                max_cost[pix] = 0.f;
-            }
-            load_left(xt + NWAVE, 0, lnext);                             // keep the operand pipeline one tile ahead
-            continue;
-        }
-        f32x4 acc[NT];
-        // right-mask bias (0 / -1e30 per right pixel = tile row) as the initial accumulator (SM_kernel.cu:48)
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            const float4 bz = *reinterpret_cast<const float4 *>(BX + (HALO + xt * 16) + 4 * q - 16 * m);
-            acc[m] = f32x4{bz.x, bz.y, bz.z, bz.w};
-        }
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-            float lv[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) lv[c] = lnext[c];
-            if (b + 1 < NBLK) load_left(xt, b + 1, lnext);               // next block of this tile
-            else load_left(xt + NWAVE, 0, lnext);                        // first block of the wave's next tile
-            i32x4 bh, bm, bl;
-            split3x8(lv, bh, bm, bl);
-            // a k group beyond the channels (C = 24: q = 3) multiplies zeros of the left operand: read any valid group
-            const int g = min(4 * b + q, CG - 1);
-            const int *ap = RT + (g * nRw + xt * 16 + j) * 4;           // tile m: + (NT - 1 - m) * 64 words
-            // one A term of ALL tiles at a time: consecutive MFMAs then go to different accumulators (no dependent
-            // back-to-back issue), smallest term pairs first
-            i32x4 at[NT];
-#pragma unroll
-            for (int m = 0; m < NT; ++m) at[m] = *reinterpret_cast<const i32x4 *>(ap + 2 * tstride + (NT - 1 - m) * 64);   // lo
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bm, acc[m]);
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bh, acc[m]);
-#pragma unroll
-            for (int m = 0; m < NT; ++m) at[m] = *reinterpret_cast<const i32x4 *>(ap + tstride + (NT - 1 - m) * 64);       // mid
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bl, acc[m]);
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bm, acc[m]);
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bh, acc[m]);
-#pragma unroll
-            for (int m = 0; m < NT; ++m) at[m] = *reinterpret_cast<const i32x4 *>(ap + (NT - 1 - m) * 64);                 // hi
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bl, acc[m]);
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bm, acc[m]);
-#pragma unroll
-            for (int m = 0; m < NT; ++m) acc[m] = mf(at[m], bh, acc[m]);
-        }
-        float mx, S, mu, var;
-        const float mu_in = (MODE == MODE_VAR && inside) ? disparity[pix] : 0.f;
-        softmax_passes<NT, MODE, 0>(acc, NT, D, dl, smem, 0, 0, 0, mu_in, mx, S, mu, var);
-        if (inside && q == 0) {
-            const bool on = rm != 0.f;
-            if (MODE != MODE_VAR) out[pix] = on ? mu : 0.f;
-            if (MODE != MODE_MAT) var_out[pix] = on ? var : 0.f;
-            sum_sim[pix] = on ? S : 0.f;
-            max_cost[pix] = on ? mx : 0.f;
-        }
-    }
-}
-
 // KQ = number of K=4 channel steps when known at compile time (C <= 4*KQ), 0 = runtime loop.
-// DK: dense rows go through dense16_body (1; C <= 8) / dense_cb_body (2; C = 9 .. 96) on the bf16 matrix cores instead of
-// the fp32 MFMA band path (0).
+// D16: dense rows go through dense16_body (bf16 matrix cores) instead of the fp32 MFMA band path.
 template <int NT, int MODE, int KQ, int PPT, int NTHR, int CAP, int NTCMAX>
 __device__ __forceinline__ int sparse_row_body(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
@@ -694,7 +548,7 @@ __device__ __forceinline__ int sparse_row_body(
     int H, int W, int D, int row, int dense_pct, int mbits);
 constexpr int MID_CAP = 640;                            // active pixels per side of a "mid-density" row (-2 marker): 55 KB of LDS
 
-template <int NT, int MODE, int KQ, int DK>
+template <int NT, int MODE, int KQ, bool D16>
 __device__ __forceinline__ void spamat_fwd_segment(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
@@ -719,8 +573,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
         }
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool D16 = DK == 1;
-    const Layout lo = make_layout(C, NT, XT, DK);
+    const Layout lo = make_layout(C, NT, XT, D16);
     float *Rs = smem + lo.offR;
     float *BX = smem + lo.offBX;
     int *XR = reinterpret_cast<int *>(BX);
@@ -762,9 +615,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const int st_nq = nRw >> 2;                      // 16-byte groups per channel row of the staged window (<= THREADS)
     const int st_rpp = THREADS / st_nq;              // channel rows per pass
     const int st_r0 = tid / st_nq, st_jq = tid - st_r0 * st_nq;
-    float4 st_v[DK ? 1 : 8];
-    float bfirst[(!DK && KQ > 0) ? KQ : 1];
-    if constexpr (!DK) {
+    float4 st_v[D16 ? 1 : 8];
+    float bfirst[(!D16 && KQ > 0) ? KQ : 1];
+    if constexpr (!D16) {
         if (st_r0 < st_rpp) {
             const int x = xs - HALO + 4 * st_jq;
 #pragma unroll
@@ -821,20 +674,6 @@ __device__ __forceinline__ void spamat_fwd_segment(
 
     int nR = 0, nL = 0;
     bool compact = false;
-    if constexpr (DK == 2) {
-        // as for D16 below: the row's path decides the LDS format of the right view
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
-        const int validL = min(SW, W - xs);
-        const int validR = min(W, xs + SW) - max(0, xs - HALO);
-        compact = allow_compact && ((long)nL * nR * 100 < (long)validL * validR * compact_pct);
-        if (!compact) {
-            dense_cb_body<NT, MODE, (KQ + 7) / 8>(reinterpret_cast<int *>(Rs), BX, LM, smem, lrow, rrow, disparity, out, var_out,
-                                                  sum_sim, max_cost, plane, rowpix, C, W, D, xs, XT, SW, HALO, nRw);
-            return;
-        }
-    }
     if constexpr (D16) {
         // the row's path decides the LDS format of the features, so the counts come first
         __syncthreads();
@@ -872,9 +711,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
             const int jj = 4 * jq, x = xs - HALO + jj;
             for (int c0 = r0; c0 < lo.Cq; c0 += 8 * rpp) {
                 float4 v[8];
-                if (!DK && c0 == r0) {                  // the first pass was requested at the top
+                if (!D16 && c0 == r0) {                 // the first pass was requested at the top
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = st_v[DK ? 0 : u];
+                    for (int u = 0; u < 8; ++u) v[u] = st_v[D16 ? 0 : u];
                 } else {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -898,7 +737,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
 
     const int validL = min(SW, W - xs);
     const int validR = min(W, xs + SW) - max(0, xs - HALO);
-    if constexpr (!DK) {
+    if constexpr (!D16) {
 #pragma unroll
         for (int w = 0; w < NWAVE; ++w) { nR += WT[w]; nL += WT[8 + w]; }
         // compact when fewer than 80 % of the candidate pairs are active (block-uniform)
@@ -907,8 +746,14 @@ __device__ __forceinline__ void spamat_fwd_segment(
 
     const int j = lane & 15, q = lane >> 4;
 
-    if constexpr (!DK) if (!compact) {
+    if constexpr (!D16) if (!compact) {
         // =========================== DENSE path ===========================================
+        // (Round 5, stages 2 / 1: ablation builds say the fp32 MFMAs below are 38 % / 52 % of the pass (0.060 -> 0.038 ms,
+        // 0.0176 -> 0.0084 without them), but moving them to the bf16 pipe -- `dense_cb_body`, 32 channels of one bf16
+        // term pair per MFMA, left operand split in registers, commit 6c42429 -- bought 0.0533 -> 0.0507 ms at stage 2
+        // and lost at stage 1 (0.0133 -> 0.0141; 0.0551 / 0.0158 with operand prefetch and term-major MFMA order): a
+        // workgroup's life is mask round trip -> staging round trip -> 3 tiles per wave, 18 us per row at two
+        // workgroups per CU, and that chain, not the arithmetic, is what the 0.053 ms are.  profiles/r05g_*, r05hi_*.)
         const int dl = j - 4 * q;                       // d = 16*m + dl - r
         float bv[KQ <= 6 ? KB : 1], bcur[KB];
         float rm = 0.f;
@@ -1144,13 +989,13 @@ __device__ __forceinline__ void spamat_fwd_segment(
 // in one workgroup, one after the other, halves the exiting workgroups of an all-sparse marker launch (-2 us) but
 // serialises a dense row's two staging phases: 0.41 -> 0.44 ms at density 1.0; a loop over segments around the
 // inlined body costs ~20 VGPR spills on top.  Measured, dropped.)
-template <int NT, int MODE, int KQ, int DK>
-__global__ __launch_bounds__(THREADS, (KQ > 6 && !DK ? 2 : 4)) void spamat_fwd_mfma(
+template <int NT, int MODE, int KQ, bool D16>
+__global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
     int H, int W, int D, int segs_per_row, int XT, int allow_compact, int marker, int compact_pct, int mbits) {
-    spamat_fwd_segment<NT, MODE, KQ, DK>(ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W,
+    spamat_fwd_segment<NT, MODE, KQ, D16>(ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W,
                                           D, XT, allow_compact, marker, blockIdx.x % segs_per_row,
                                           blockIdx.x / segs_per_row, compact_pct, mbits);
 }
@@ -1203,6 +1048,11 @@ __device__ __forceinline__ int sparse_row_body(
     int *XL = reinterpret_cast<int *>(smem) + offXL;
     int *WT = reinterpret_cast<int *>(smem) + offWT;
     float *RF = smem + offRF, *LF = smem + offLF;
+    // (Round 5: the mid-density body with its compacted features as bf16 terms -- cost tiles on v_mfma_f32_16x16x32_bf16
+    // as in dense16_body, split where a pixel is compacted -- was built and measured SLOWER at every density below 0.6
+    // (0.3: 0.128 -> 0.137 ms, 0.5: 0.189 -> 0.202): the split runs under the compaction's divergence, 350 vector
+    // instructions per wave whatever the density, and an operand fetch is 16 bytes per lane instead of 4.
+    // profiles/r05j_mid_body_bf16x3_tiles.txt.)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = row / H, y = row - b * H;
@@ -1469,9 +1319,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     // DECNET_SPAMAT_DENSE=fp32 or the compaction paths are pinned off; it needs more LDS per staged position
     static const int dense_fp32 = [] { const char *e = getenv("DECNET_SPAMAT_DENSE"); return e && !strcmp(e, "fp32"); }();
     // (C = 24, three channel groups to split per staged position: 0.080 vs 0.062 ms at stage 2 -- stays on fp32 MFMA)
-    // (round 5: C = 24 / 72 through dense_cb_body -- 32 channels of one term pair per MFMA, the left operand split in
-    // registers -- stage 2 0.053 -> see profiles/r05h_*; DECNET_SPAMAT_DENSE=fp32 keeps every stage on fp32 MFMA)
-    const int d16 = dense_fp32 ? 0 : KQ == 2 ? 1 : (KQ == 6 || KQ == 18) ? 2 : 0;
+    const bool d16 = KQ == 2 && !dense_fp32;
     auto bytes = [&](int xt) { return (size_t)4 * make_layout(C, NT, xt, d16).total; };
     // whole row per workgroup when two workgroups (16 waves) still fit a CU's LDS; otherwise
     // equal segments that do; otherwise whatever fits once.  Segments hold <= 64 tiles so that
@@ -1560,13 +1408,10 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
 #define LAUNCH(M)                                                                                  \
     do {                                                                                           \
         if constexpr (KQ == 2) {                                                                   \
-            if (d16) LAUNCH1(M, 1);                                                                \
-            else LAUNCH1(M, 0);                                                                    \
-        } else if constexpr (KQ == 6 || KQ == 18) {                                                \
-            if (d16) LAUNCH1(M, 2);                                                                \
-            else LAUNCH1(M, 0);                                                                    \
+            if (d16) LAUNCH1(M, true);                                                             \
+            else LAUNCH1(M, false);                                                                \
         } else {                                                                                   \
-            LAUNCH1(M, 0);                                                                         \
+            LAUNCH1(M, false);                                                                     \
         }                                                                                          \
     } while (0)
     if (mode == MODE_MAT) LAUNCH(MODE_MAT);
