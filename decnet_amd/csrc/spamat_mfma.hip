@@ -1048,6 +1048,12 @@ __device__ __forceinline__ int sparse_row_body(
     int *XL = reinterpret_cast<int *>(smem) + offXL;
     int *WT = reinterpret_cast<int *>(smem) + offWT;
     float *RF = smem + offRF, *LF = smem + offLF;
+    // (Round 5: a launch of their own for the mid rows -- this body with 576 slots, 10 tiles per chunk, the left view
+    // requested behind the right view's compaction: 51 KB and 80 registers without spills, THREE 8-wave workgroups per
+    // CU instead of two -- gains 10 % at densities 0.3 - 0.4 (0.130 -> 0.117 ms) and loses everywhere else: rows it
+    // cannot take are scanned a third time (0.6: 0.235 -> 0.271), and an input without mid rows pays 4.5 us for its
+    // exits (0.1: 0.078 -> 0.082).  With registers spilling (12 tiles, two rows per workgroup) every launch of it pays
+    // the scratch set-up: +25 us.  profiles/r05l_mid_rows_own_launch.txt.)
     // (Round 5: the mid-density body with its compacted features as bf16 terms -- cost tiles on v_mfma_f32_16x16x32_bf16
     // as in dense16_body, split where a pixel is compacted -- was built and measured SLOWER at every density below 0.6
     // (0.3: 0.128 -> 0.137 ms, 0.5: 0.189 -> 0.202): the split runs under the compaction's divergence, 350 vector

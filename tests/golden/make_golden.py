@@ -207,9 +207,50 @@ def e2e_case():
     return rec
 
 
+def full_inputs(B, C, H, W, seed):
+    """Stage-0 feature maps of a full-size case from numpy's frozen RandomState stream (the same on every host; the .npz
+    stores only their CRC32): post-ReLU N(0, 1) like the real extractor's outputs."""
+    rs = np.random.RandomState(seed)
+    left = np.maximum(rs.standard_normal((B, C, H, W)), 0).astype(np.float32)
+    right = np.maximum(rs.standard_normal((B, C, H, W)), 0).astype(np.float32)
+    return left, right
+
+
+def stage0_full_case(sub, C, B, H, W, D, seed):
+    """BASELINE config 2's full stage-0 shape (216 channels, 20 x 36, D = 8) through the REFERENCE's classes; every op is
+    per sample; B = 8 is the whole batch of the bench step.  Outputs only (the cost volume alone would be 40 MB)."""
+    import zlib
+    ln, rn = full_inputs(B, C, H, W, seed)
+    left, right = torch.from_numpy(ln), torch.from_numpy(rn)
+    gcv = sub.GetCostVolume(warp_ope="homgrp", cost_func="cor")
+    reg = sub.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func="cor", down_scale=3)
+    params = o0.random_params(C, seed + 1000)
+    load_params(reg, params)
+    reg.eval()
+    with torch.no_grad():
+        ds = sub.get_disp_samples(D, left, stage_id=0)
+        cv = gcv(left, right, disp_samples=ds, max_disp=D)
+        r = reg(cv.clone())
+        pred = sub.disparity_regression(r, ds)
+    return dict(shape=np.array([B, C, H, W], np.int64), max_disp=np.int64(D), input_seed=np.int64(seed),
+                input_crc=np.int64(zlib.crc32(ln.tobytes() + rn.tobytes())), param_seed=np.int64(seed + 1000),
+                w0_checksum=np.float64(params[0]["w"].double().sum().item()),
+                w7_checksum=np.float64(params[7]["w"].double().abs().sum().item()),
+                cost_vol_abs_sum=np.float64(cv.double().abs().sum().item()), reg=r.numpy(), pred=pred.numpy())
+
+
 def main():
     install_stubs()
     import modules.submodule as sub
+    if "--only-stage0-full" in sys.argv:               # (minutes of CPU: 203 GFLOP through torch's Conv3d)
+        np.savez_compressed(os.path.join(HERE, "stage0_cfg2_full.npz"),
+                            **stage0_full_case(sub, C=216, B=8, H=20, W=36, D=8, seed=11))
+        # config 3 (KITTI, 4 pairs per GPU) and config 4 (Middlebury half-res, max_disp 270 -> D = 10)
+        np.savez_compressed(os.path.join(HERE, "stage0_cfg3_full.npz"),
+                            **stage0_full_case(sub, C=216, B=4, H=14, W=46, D=8, seed=12))
+        np.savez_compressed(os.path.join(HERE, "stage0_cfg4_full.npz"),
+                            **stage0_full_case(sub, C=216, B=1, H=38, W=56, D=10, seed=13))
+        return
     np.savez_compressed(os.path.join(HERE, "stage0_small.npz"),
                         **stage0_case(sub, C=12, B=2, H=5, W=9, D=4, seed=5, store_params=True))
     np.savez_compressed(os.path.join(HERE, "stage0_c216.npz"),

@@ -51,6 +51,30 @@ def test_stage0_c216_matches_reference_and_seeded_params_are_stable(golden_dir):
     np.testing.assert_allclose(pred.numpy(), d["pred"], rtol=0, atol=1e-4)
 
 
+def full_case_inputs(d):
+    """The feature maps of stage0_cfg2_full.npz: regenerated from numpy's frozen RandomState stream, CRC-checked."""
+    import zlib
+    B, C, H, W = (int(v) for v in d["shape"])
+    rs = np.random.RandomState(int(d["input_seed"]))
+    left = np.maximum(rs.standard_normal((B, C, H, W)), 0).astype(np.float32)
+    right = np.maximum(rs.standard_normal((B, C, H, W)), 0).astype(np.float32)
+    assert zlib.crc32(left.tobytes() + right.tobytes()) == int(d["input_crc"]), "input stream changed"
+    return torch.from_numpy(left), torch.from_numpy(right)
+
+
+def test_stage0_full_size_golden_pins_the_oracle(golden_dir):
+    """BASELINE config 2's whole stage-0 batch (8 x 216 x 20 x 36, D = 8) through the REFERENCE's GetCostVolume /
+    CostRegNetNoDown / disparity_regression (tests/golden/make_golden.py --only-stage0-full): oracle/stage0.py on two of
+    the eight samples (every op is per sample; the GPU test takes all eight)."""
+    d = _load(golden_dir, "stage0_cfg2_full.npz")
+    params = o0.random_params(216, int(d["param_seed"]))
+    assert abs(params[0]["w"].double().sum().item() - float(d["w0_checksum"])) < 1e-9
+    left, right = full_case_inputs(d)
+    pred, reg, cv = o0.stage0_forward(left[5:7], right[5:7], params, int(d["max_disp"]))
+    np.testing.assert_allclose(reg.numpy(), d["reg"][5:7], rtol=0, atol=1e-4 * max(1.0, float(np.abs(d["reg"]).max())))
+    np.testing.assert_allclose(pred.numpy(), d["pred"][5:7], rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("name", ["stage0_small.npz", "stage0_c216.npz"])
 def test_closed_form_warp_equals_grid_sample(golden_dir, name):
     """the stretched, half-pixel-shifted bilinear warp in closed form."""

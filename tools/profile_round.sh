@@ -18,7 +18,7 @@ cd $R
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/${TAG}_pmc_traffic_raw.json $O/traffic.json $O/${TAG}_bench_kernel_stats.csv
 # the sparse-row forward (spamat_fwd_sparse + marker launch of spamat_fwd_mfma), one density per pass pair
-for d in 0.10 0.05 0.02; do
+for d in 0.50 0.30 0.10 0.05 0.02; do
   cd /tmp
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_sf_$d -o f -- python3 $R/tools/bench_spamat.py --stage 3 --density $d --iters 5 > /dev/null 2> $O/pmc_sf_$d.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_sw_$d -o w -- python3 $R/tools/bench_spamat.py --stage 3 --density $d --iters 5 > /dev/null 2> $O/pmc_sw_$d.err
