@@ -77,6 +77,13 @@ __device__ __forceinline__ int mask4_bits(const unsigned long long *__restrict__
     return (int)((rowbits[x >> 6] >> (x & 63)) & 15ull);
 }
 
+// the same out of a row of 32-bit words (bit i of word w = pixel 32 w + i): the masks the sparse-row kernel hands over to the
+// band kernel in the row's own max_cost entries (mbits = 2, see spamat_fwd_sparse)
+__device__ __forceinline__ int mask4_words(const unsigned *__restrict__ roww, int x, int W) {
+    if (x < 0 || x >= W) return 0;
+    return (int)((roww[x >> 5] >> (x & 31)) & 15u);
+}
+
 // fp32 -> three bf16 terms x = hi + mid + lo (truncations with exact residuals: 24 mantissa bits
 // together), 8 values -> three packed 8 x bf16 MFMA operands.
 __device__ __forceinline__ void split3x8(const float (&x)[8], i32x4 &hi, i32x4 &mid, i32x4 &lo) {
@@ -545,7 +552,7 @@ __device__ __forceinline__ int sparse_row_body(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int row, int dense_pct, int mbits);
+    int H, int W, int D, int row, int dense_pct, int mbits, int *fr_out = nullptr, int *fl_out = nullptr);
 constexpr int MID_CAP = 640;                            // active pixels per side of a "mid-density" row (-2 marker): 55 KB of LDS
 
 template <int NT, int MODE, int KQ, bool D16>
@@ -642,7 +649,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
         const bool alm = (((uintptr_t)trow) & 15) == 0 && (((uintptr_t)mrow) & 15) == 0;
         if (p4 < nRw) {
             const int x = xs - HALO + p4;
-            if (mbits) {
+            if (mbits == 2) {
+                fr = mask4_words(reinterpret_cast<const unsigned *>(max_cost + rowpix), x, W);
+            } else if (mbits) {
                 fr = mask4_bits(tbits, x, W);
             } else {
                 float4 tv = load4(trow, x, W, alm);
@@ -658,7 +667,8 @@ __device__ __forceinline__ void spamat_fwd_segment(
         if (p4 < SW) {
             float4 mv;
             if (mbits) {
-                fl = mask4_bits(lbits, xs + p4, W);
+                fl = mbits == 2 ? mask4_words(reinterpret_cast<const unsigned *>(max_cost + rowpix) + ((W + 31) >> 5), xs + p4, W)
+                                : mask4_bits(lbits, xs + p4, W);
                 mv = make_float4((fl & 1) ? 1.f : 0.f, (fl & 2) ? 1.f : 0.f, (fl & 4) ? 1.f : 0.f, (fl & 8) ? 1.f : 0.f);
             } else {
                 mv = load4(mrow, xs + p4, W, alm);
@@ -1031,7 +1041,7 @@ __device__ __forceinline__ int sparse_row_body(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int row, int dense_pct, int mbits) {
+    int H, int W, int D, int row, int dense_pct, int mbits, int *fr_out, int *fl_out) {
     // at most 8 cost tiles per span (32 accumulator registers: six workgroups per CU); a row whose
     // disparity windows hold more than 8*16-15 active right pixels even for 16-pixel spans goes to
     // spamat_fwd_mfma like the dense ones
@@ -1089,7 +1099,11 @@ __device__ __forceinline__ int sparse_row_body(
 #pragma unroll
         for (int u = 0; u < PPT; u += 4) {
             if (p4 + u < W) {
-                if (mbits) {
+                if (mbits == 2) {                       // handed over by the sparse-row kernel (inside the band kernel only)
+                    const unsigned *hw = reinterpret_cast<const unsigned *>(max_cost + rowpix);
+                    fr |= mask4_words(hw, p4 + u, W) << u;
+                    fl |= mask4_words(hw + ((W + 31) >> 5), p4 + u, W) << u;
+                } else if (mbits) {
                     const int wpr = (W + 63) >> 6;
                     fr |= mask4_bits(reinterpret_cast<const unsigned long long *>(tmask) + (size_t)row * wpr, p4 + u, W) << u;
                     fl |= mask4_bits(reinterpret_cast<const unsigned long long *>(rmask) + (size_t)row * wpr, p4 + u, W) << u;
@@ -1101,6 +1115,7 @@ __device__ __forceinline__ int sparse_row_body(
             }
         }
     }
+    if (fr_out) { *fr_out = fr; *fl_out = fl; }
     const int cr = __popc(fr), cl = __popc(fl);
     const int ir = wave_incl_scan(cr, lane), il = wave_incl_scan(cl, lane);
     if (lane == 63) { WT[wave] = ir; WT[8 + wave] = il; }
@@ -1303,16 +1318,36 @@ __global__ __launch_bounds__(SP_THREADS, PPT == 4 ? 6 : 5) void spamat_fwd_spars
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity, float *__restrict__ out,
     float *__restrict__ var_out, float *__restrict__ sum_sim, float *__restrict__ max_cost, int C,
-    int H, int W, int D, int seg_w, int dense_pct, int mbits) {
+    int H, int W, int D, int seg_w, int dense_pct, int mbits, int handover) {
     const int row = blockIdx.x;
+    int fr = 0, fl = 0;
     const int rc = sparse_row_body<NT, MODE, KQ, PPT, SP_THREADS, SP_CAP, 8>(ref, tar, rmask, tmask, disparity, out, var_out,
-                                                                            sum_sim, max_cost, C, H, W, D, row, dense_pct, mbits);
+                                                                            sum_sim, max_cost, C, H, W, D, row, dense_pct, mbits,
+                                                                            &fr, &fl);
     if (rc != 1) {
         // left to spamat_fwd_mfma (marker launch): a negative value at the first pixel of every segment of the row (a
         // real sum_similarities is never negative); -2: <= 512 active pixels per side, worth the 512-slot body there
         const size_t rowpix = (size_t)row * W;
         const float mark = rc == 2 ? -2.0f : -1.0f;
         for (int x = threadIdx.x * seg_w; x < W; x += SP_THREADS * seg_w) sum_sim[rowpix + x] = mark;
+        // handover (round 5): this workgroup has read both float mask rows (7.8 KB at 972 pixels) to find out that the row
+        // is not its; the band kernel would read them again (PMC: 1.12 x the algorithmic bytes at mid densities, 1.08 x
+        // on dense rows).  The activity bits go along instead -- 2 ceil(W / 32) words at the start of the row's own
+        // max_cost entries, which nobody needs before the band kernel's workgroup of this row writes its results there.
+        if (handover) {
+            extern __shared__ __attribute__((aligned(16))) float smem[];
+            unsigned *wb = reinterpret_cast<unsigned *>(smem);
+            const int nw = (W + 31) >> 5, p4 = threadIdx.x * PPT;
+            __syncthreads();                              // the body's LDS arrays are dead
+            for (int i = threadIdx.x; i < 2 * nw; i += SP_THREADS) wb[i] = 0u;
+            __syncthreads();
+            if (p4 < W) {
+                if (fr) atomicOr(&wb[p4 >> 5], (unsigned)fr << (p4 & 31));
+                if (fl) atomicOr(&wb[nw + (p4 >> 5)], (unsigned)fl << (p4 & 31));
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < 2 * nw; i += SP_THREADS) reinterpret_cast<unsigned *>(max_cost + rowpix)[i] = wb[i];
+        }
     }
 }
 
@@ -1366,6 +1401,11 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     // DECNET_SPAMAT_MID=0 switches it off (a separate 256-thread launch for these rows was measured slower: tools/experiments)
     static const bool mid_off = [] { const char *e = getenv("DECNET_SPAMAT_MID"); return e && atoi(e) == 0; }();
     size_t lds_launch = lds;
+    // the sparse-row kernel hands the activity bits of the rows it leaves to the band kernel (whole rows per workgroup,
+    // float masks, room for 2 ceil(W / 32) words in a row of max_cost; DECNET_SPAMAT_HANDOVER=0: the band kernel reads
+    // the float planes again)
+    static const bool handover_off = [] { const char *e = getenv("DECNET_SPAMAT_HANDOVER"); return e && atoi(e) == 0; }();
+    const int handover = (KQ > 0 && KQ <= 6 && marker && segs == 1 && !mbits && 2 * ((W + 31) / 32) <= W && !handover_off) ? 1 : 0;
     if (KQ == 2 && marker && segs == 1 && !mid_off) {
         const size_t need = 4 * sparse_row_words(KQ, 4, THREADS, MID_CAP);
         if (need <= budget2 + 8192) {
@@ -1385,7 +1425,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_sparse<NT, M, (KQ ? KQ : 1), P>), dim3((unsigned)(B * H)),  \
                            dim3(SP_THREADS), slds, stream, ref, tar, rmask, tmask, disparity, out, \
-                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16, sparse_pct, mbits);    \
+                           var_out, sum_sim, max_cost, C, H, W, D, XT * 16, sparse_pct, mbits, handover); \
     } while (0)
 #define LAUNCHSP(M)                                                                                \
     do {                                                                                           \
@@ -1409,7 +1449,7 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
         }                                                                                          \
         hipLaunchKernelGGL((spamat_fwd_mfma<NT, M, KQ, DD>), grid, block, lds_launch, stream, ref, tar, rmask, \
                            tmask, disparity, out, var_out, sum_sim, max_cost, C, H, W, D, segs, XT, \
-                           allow_compact, marker, compact_pct, mbits);                             \
+                           allow_compact, marker, compact_pct, handover ? 2 : mbits);              \
     } while (0)
 #define LAUNCH(M)                                                                                  \
     do {                                                                                           \
