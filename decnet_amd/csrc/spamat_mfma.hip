@@ -461,6 +461,9 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
         }
     }
     __syncthreads();
+#if DECNET_ABLATE == 7      // timing-only: masks + both staging phases of a dense row, no cost tiles, no softmax
+    return;
+#endif
 
     const int j = lane & 15, q = lane >> 4;
     const int dl = j - 4 * q;                                            // d = 16 m + dl - r
