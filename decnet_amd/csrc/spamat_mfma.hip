@@ -1416,6 +1416,9 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
             if (need > lds_launch) lds_launch = need;
         }
     }
+#ifdef DECNET_DEV_STAGE3       // occupancy experiments: DECNET_SPAMAT_LDS_PAD_KB more LDS per band-kernel workgroup
+    { const char *e = getenv("DECNET_SPAMAT_LDS_PAD_KB"); if (e) lds_launch += (size_t)atoi(e) * 1024; }
+#endif
     if constexpr (KQ > 0 && KQ <= 6) if (marker) {
         const int ppt = W <= 1024 ? 4 : 8;
         const size_t slds = 4 * sparse_row_words(KQ, ppt, SP_THREADS, SP_CAP);
