@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void count_nonfinite(const float *__restrict__
         bad += ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) + ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) +
                ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u) + ((__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3))                         // tail
-        bad += (__float_as_uint(x[4 * n4 + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)   // tail (everything when
+        bad += (__float_as_uint(x[i]) & 0x7f800000u) == 0x7f800000u;                                // the map is not 16-byte aligned)
     for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
 }
@@ -75,13 +75,14 @@ static int check_finite(const float *ref, const float *tar, int B, int C, int H,
         (void)hipGetLastError();
         return 0;
     }
-    if ((((uintptr_t)ref) | ((uintptr_t)tar)) & 15) return 0;             // (torch allocations are 512-byte aligned)
+    const bool aligned = ((((uintptr_t)ref) | ((uintptr_t)tar)) & 15) == 0;   // (torch allocations are; a view may not be)
     unsigned *d = nullptr, h = 0;
     hipError_t e = hipMallocAsync((void **)&d, sizeof(unsigned), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(d, 0, sizeof(unsigned), stream);
-    const size_t n = (size_t)B * C * H * W, n4 = n >> 2;
-    const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 + 1 : 2048);
+    const size_t n = (size_t)B * C * H * W, n4 = aligned ? n >> 2 : 0;
+    const size_t nwork = aligned ? n4 : n;
+    const unsigned grid = (unsigned)((nwork + 255) / 256 < 2048 ? (nwork + 255) / 256 + 1 : 2048);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(count_nonfinite, dim3(grid), dim3(256), 0, stream, ref, n4, n, d);
         hipLaunchKernelGGL(count_nonfinite, dim3(grid), dim3(256), 0, stream, tar, n4, n, d);

@@ -40,6 +40,15 @@ CHILD = textwrap.dedent("""
                 raise SystemExit("compiled module accepted a non-finite input")
             except RuntimeError as e:
                 assert "-4" in str(e), str(e)
+    # feature maps that are not 16-byte aligned (a view into a larger buffer) are checked too
+    big = torch.zeros(2 * 8 * 6 * 333 + 1, device=dev)
+    Lu = big[1:].view(2, 8, 6, 333); Lu.copy_(L); Lu[1, 2, 3, 4] = float("inf")
+    assert Lu.data_ptr() % 16 != 0
+    try:
+        decnet_amd.spamatvar_forward(Lu, R, m, m, 216, out=(o, v, s, mx))
+        raise SystemExit("non-finite element of an unaligned map accepted")
+    except _lib.DecnetHipError as e:
+        assert e.code == -4, e.code
     # under stream capture the check (which has to wait for the stream) is skipped, not an error
     gph = torch.cuda.CUDAGraph()
     st = torch.cuda.Stream()
