@@ -45,6 +45,18 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, in
     }
     return v;
 }
+// Round 5, from the ISA: several load4() calls in a row are SERIAL memory round trips -- both sides of its per-lane branch
+// write the same registers and the compiler puts `s_waitcnt vmcnt(0)` in front of every wide load (80 of the 81 wide loads
+// of the C = 72 instantiation).  Where a thread has a batch of them, the batch is issued as raw 16-byte loads from clamped
+// addresses behind a WORKGROUP-UNIFORM flag (rows on 16-byte boundaries, W a multiple of 4: a group of four is inside or
+// outside its row as a whole, x being a multiple of 4), a scheduling barrier, and the zeros are selected afterwards.
+__device__ __forceinline__ bool uniform_flag(bool f) { return __builtin_amdgcn_readfirstlane((int)f) != 0; }
+__device__ __forceinline__ float4 load4_raw(const float *__restrict__ safe, const float *__restrict__ at, bool ok) {
+    return *reinterpret_cast<const float4 *>(ok ? at : safe);
+}
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
 
 struct BLayout {
     int SW, HALO, OW, OP, Cq, offP, total;
@@ -104,6 +116,8 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
         const bool alp = (rowpix & 3) == 0 && ((((uintptr_t)oth_mask) | ((uintptr_t)out) |
                                                 ((uintptr_t)sum_sim) | ((uintptr_t)max_cost) |
                                                 ((uintptr_t)grad_out)) & 15) == 0;
+        const bool alu = uniform_flag(al && (W & 3) == 0);      // batches of raw loads, see load4_raw
+        const bool alpu = uniform_flag(alp && (W & 3) == 0 && (!VAR || (((uintptr_t)disparity) & 15) == 0));
         // features: threads spread over (channel row, group of 4 positions), up to 8 loads in flight each
         // (stage 1, C = 72 over 144 positions: 6 loads per thread instead of 72 serial ones on 36 threads)
         const int nq = OW >> 2;
@@ -111,12 +125,24 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
             const int rpp = THREADS / nq, r0 = tid / nq, jq = tid - r0 * nq;
             if (r0 < rpp) {
                 const int jj = 4 * jq, x = xo0 + jj;
+                const bool inx = x >= 0 && x < W;
                 for (int c0 = r0; c0 < lo.Cq; c0 += 8 * rpp) {
                     float4 v[8];
+                    if (alu) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c = c0 + u * rpp;
-                        v[u] = c < C ? load4(oth_row + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = c0 + u * rpp;
+                            v[u] = load4_raw(oth_row, oth_row + (size_t)c * plane + x, inx && c < C);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = sel4(inx && c0 + u * rpp < C, v[u]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = c0 + u * rpp;
+                            v[u] = c < C ? load4(oth_row + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -131,33 +157,65 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
             if (nq > THREADS) {
                 for (int c0 = 0; c0 < lo.Cq; c0 += 8) {
                     float4 v[8];
+                    if (alu) {
+                        const bool inx = x >= 0 && x < W;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        v[c] = c0 + c < C ? load4(oth_row + (size_t)(c0 + c) * plane, x, W, al)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int c = 0; c < 8; ++c)
+                            v[c] = load4_raw(oth_row, oth_row + (size_t)(c0 + c) * plane + x, inx && c0 + c < C);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = sel4(inx && c0 + c < C, v[c]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            v[c] = c0 + c < C ? load4(oth_row + (size_t)(c0 + c) * plane, x, W, al)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
                         if (c0 + c < lo.Cq) *reinterpret_cast<float4 *>(Os + (c0 + c) * OP + j) = v[c];
                 }
             }
-            const float4 mk = load4(oth_mask, x, W, alp);
+            float4 mk, mx, oo, gg, ss, dd;
+            if (alpu) {
+                const bool inx = x >= 0 && x < W;
+                mk = load4_raw(oth_mask, oth_mask + x, inx);
+                if (SIDE == 1) {
+                    mx = load4_raw(oth_mask, max_cost + rowpix + x, inx);
+                    oo = load4_raw(oth_mask, out + rowpix + x, inx);
+                    gg = load4_raw(oth_mask, grad_out + rowpix + x, inx);
+                    ss = load4_raw(oth_mask, sum_sim + rowpix + x, inx);
+                    if (VAR) dd = load4_raw(oth_mask, disparity + rowpix + x, inx);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mk = sel4(inx, mk);
+                if (SIDE == 1) {
+                    mx = sel4(inx, mx); oo = sel4(inx, oo); gg = sel4(inx, gg); ss = sel4(inx, ss);
+                    if (VAR) dd = sel4(inx, dd);
+                }
+            } else {
+                mk = load4(oth_mask, x, W, alp);
+                if (SIDE == 1) {
+                    mx = load4(max_cost + rowpix, x, W, alp);
+                    oo = load4(out + rowpix, x, W, alp);
+                    gg = load4(grad_out + rowpix, x, W, alp);
+                    ss = load4(sum_sim + rowpix, x, W, alp);
+                    if (VAR) dd = load4(disparity + rowpix, x, W, alp);
+                }
+            }
             const bool on[4] = {x >= 0 && x < W && mk.x != 0.f, x + 1 >= 0 && x + 1 < W && mk.y != 0.f,
                                 x + 2 >= 0 && x + 2 < W && mk.z != 0.f, x + 3 >= 0 && x + 3 < W && mk.w != 0.f};
             float4 bz = make_float4(on[0] ? 0.f : NEG_BIG, on[1] ? 0.f : NEG_BIG, on[2] ? 0.f : NEG_BIG,
                                     on[3] ? 0.f : NEG_BIG);
             *reinterpret_cast<float4 *>(PL + j) = bz;
             if (SIDE == 1) {
-                const float4 mx = load4(max_cost + rowpix, x, W, alp);
-                const float4 oo = load4(out + rowpix, x, W, alp);
-                const float4 gg = load4(grad_out + rowpix, x, W, alp);
-                const float4 ss = load4(sum_sim + rowpix, x, W, alp);
                 *reinterpret_cast<float4 *>(PL + OW + j) =
                     make_float4(-mx.x * LOG2E, -mx.y * LOG2E, -mx.z * LOG2E, -mx.w * LOG2E);
                 *reinterpret_cast<float4 *>(PL + 2 * OW + j) = oo;
                 *reinterpret_cast<float4 *>(PL + 3 * OW + j) =          // g/S, 0 where the left mask is off
                     make_float4(on[0] ? gg.x / ss.x : 0.f, on[1] ? gg.y / ss.y : 0.f,
                                 on[2] ? gg.z / ss.z : 0.f, on[3] ? gg.w / ss.w : 0.f);
-                if (VAR) *reinterpret_cast<float4 *>(PL + 4 * OW + j) = load4(disparity + rowpix, x, W, alp);
+                if (VAR) *reinterpret_cast<float4 *>(PL + 4 * OW + j) = dd;
             }
         }
     }

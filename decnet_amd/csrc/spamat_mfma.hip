@@ -57,7 +57,27 @@ constexpr int THREADS = 512, NWAVE = THREADS / 64;
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // 4 consecutive floats row[x .. x+3], zeros outside [0, W); one 16-byte load when possible.
-__device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, int W, bool aligned) {
+// Four consecutive values row[x .. x + 3] (zeros outside [0, W)), x a multiple of 4, in two forms chosen by a
+// WORKGROUP-UNIFORM flag `al` (uniform_flag(): the rows start on 16-byte boundaries and W is a multiple of 4, so a group
+// lies inside or outside its row as a whole):
+//   load4f  ONE unconditional 16-byte load -- lanes that are outside (or whose channel does not exist: `ok`) read `safe`,
+//           any aligned readable address -- and a select (SEL = false: no select; for callers whose outside lanes are
+//           finite-but-ignored: right pixels outside the row carry the -1e30 bias, left pixels outside it are not stored);
+//   load4s  four guarded 4-byte loads.
+// Round 5, from the ISA: the earlier per-lane `if (inside) wide load else four guarded loads` has both sides writing the
+// same registers, and the compiler orders them with `s_waitcnt vmcnt(0)` in front of EVERY wide load -- a staging item's
+// eight loads were eight serial memory round trips (stage 3 dense rows: 0.10 of 0.42 ms; stages 1 - 2 and the mid-density
+// body likewise).  Call sites branch ONCE on the flag around all of their loads.
+__device__ __forceinline__ bool uniform_flag(bool f) { return __builtin_amdgcn_readfirstlane((int)f) != 0; }
+template <bool SEL = true>
+__device__ __forceinline__ float4 load4f(const float *__restrict__ safe, const float *__restrict__ row, int x, int W, bool ok) {
+    const bool in = ok && x >= 0 && x < W;
+    const float4 t = *reinterpret_cast<const float4 *>(in ? row + x : safe);
+    if (!SEL) return t;                                 // the caller never uses the outside lanes' values as numbers that count
+    return make_float4(in ? t.x : 0.f, in ? t.y : 0.f, in ? t.z : 0.f, in ? t.w : 0.f);
+}
+// the per-lane form (sparse-row bodies only: two mask loads, or loads whose lanes are all inside)
+__device__ __forceinline__ float4 load4_lanes(const float *__restrict__ row, int x, int W, bool aligned) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (aligned && x >= 0 && x + 3 < W) {
         v = *reinterpret_cast<const float4 *>(row + x);
@@ -67,6 +87,14 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ row, int x, in
         if (x + 2 >= 0 && x + 2 < W) v.z = row[x + 2];
         if (x + 3 >= 0 && x + 3 < W) v.w = row[x + 3];
     }
+    return v;
+}
+__device__ __forceinline__ float4 load4s(const float *__restrict__ row, int x, int W) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= 0 && x < W) v.x = row[x];
+    if (x + 1 >= 0 && x + 1 < W) v.y = row[x + 1];
+    if (x + 2 >= 0 && x + 2 < W) v.z = row[x + 2];
+    if (x + 3 >= 0 && x + 3 < W) v.w = row[x + 3];
     return v;
 }
 
@@ -111,6 +139,11 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], i32x4 &hi, i32x4 &
 //   LM [SW+16]    dense: left mask;  compact: exclusive prefix count of active left pixels
 //   XL [SW]       compacted left positions
 //   WT [32]       scan scratch
+// dense16_body's term planes keep position p at 16-byte slot (p % 4) * P + p / 4: a staging thread's four positions go to
+// four runs of consecutive slots (its neighbours' next to them: no bank conflicts on the ds_write_b128; with position-major
+// slots the lanes were 64 bytes apart, a 4-way conflict = the 15 % conflict cycles the SQ counters showed), and the sixteen
+// lanes of an operand read touch sixteen different slots mod 16 when P % 8 == 4.
+__host__ __device__ inline int d16_pitch(int quads) { return quads + ((4 - quads) & 7); }
 struct Layout {
     int SW, HALO, RP, Cq;
     int offR, offBX, offRK, offLM, offXL, offWT, total;
@@ -124,7 +157,7 @@ __host__ __device__ inline Layout make_layout(int C, int NT, int XT, bool d16 = 
     l.offR = 0;
     // (D16: the same region holds both views as bf16 terms, dense16_body)
     const int swh = ((XT + 1) / 2) * 16;                             // dense16_body runs on half a segment at a time
-    const int rt = d16 ? 3 * ((C + 7) / 8) * (l.HALO + 2 * swh) * 4 : 0;
+    const int rt = d16 ? 3 * ((C + 7) / 8) * 16 * (d16_pitch((l.HALO + swh) >> 2) + d16_pitch(swh >> 2)) : 0;
     l.offBX = l.offR + (l.Cq * l.RP > rt ? l.Cq * l.RP : rt);
     l.offRK = l.offBX + l.RP;
     l.offLM = l.offRK + l.RP + 4;
@@ -396,11 +429,34 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
 // ~5 % of the softmax work instead of ~20 %.  LDS: 48 bytes per staged position and channel group for each
 // side, so a 972-pixel row of stage 3 is two segments (63 KB each, two workgroups per CU).
 // BX (right-mask bias) and LM (left mask) are filled by the caller's phase 1.
+// 8 channel rows x 4 positions of one view.  Positions outside the row are NOT zeroed on the aligned path (they read the
+// row's first group): a right pixel outside the row has the -1e30 bias (BX: its mask reads as 0), a left pixel outside it
+// is never stored.  Channels that do not exist are zeros.
+__device__ __forceinline__ void dense16_loads8(float4 (&v)[8], const float *__restrict__ src, size_t plane, int g, int C,
+                                               int x, int W, bool al) {
+    if (al) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = load4f<false>(src, src + (size_t)(8 * g + c) * plane, x, W, 8 * g + c < C);
+        __builtin_amdgcn_sched_barrier(0);              // all eight requests before anything that waits for one
+        if (C & 7) {                                    // (uniform) a partial channel group: its missing channels are zeros
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bool ch = 8 * g + c < C;
+                v[c] = make_float4(ch ? v[c].x : 0.f, ch ? v[c].y : 0.f, ch ? v[c].z : 0.f, ch ? v[c].w : 0.f);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            v[c] = 8 * g + c < C ? load4s(src + (size_t)(8 * g + c) * plane, x, W) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // the loads of staging item `it` of dense16_body(xs, SW, HALO, nRw): 8 channels x 4 positions of one view
 __device__ __forceinline__ void dense16_item_loads(float4 (&v)[8], int it, const float *__restrict__ lrow,
                                                    const float *__restrict__ rrow, size_t plane, int C, int W, int xs,
                                                    int SW, int HALO, int nRw) {
-    const bool al = ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+    const bool al = uniform_flag((W & 3) == 0 && ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0);
     const int cg_n = (C + 7) >> 3, nqR = nRw >> 2, nqL = SW >> 2;
     const int nR_items = cg_n * nqR;
     const bool isL = it >= nR_items;
@@ -408,9 +464,7 @@ __device__ __forceinline__ void dense16_item_loads(float4 (&v)[8], int it, const
     const int g = k / nq, jq = k - g * nq;
     const float *src = isL ? lrow : rrow;
     const int x = isL ? xs + 4 * jq : xs - HALO + 4 * jq;
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        v[c] = 8 * g + c < C ? load4(src + (size_t)(8 * g + c) * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dense16_loads8(v, src, plane, g, C, x, W, al);
 }
 
 // pre: the loads of this thread's first staging item (it = tid), requested by the caller before the mask phase (PRE)
@@ -423,10 +477,11 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
                                              int D, int xs, int XT, int SW, int HALO, int nRw, const float4 *pre = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     struct { int CG; } lo = {(C + 7) >> 3};
-    int *LT = RT + 3 * lo.CG * nRw * 4;
+    const int PR = d16_pitch(nRw >> 2), PL = d16_pitch(SW >> 2);          // slots per (term, group, p % 4) run
+    int *LT = RT + 3 * lo.CG * 16 * PR;
     // ---- features of both views: 8 channels x 4 positions per item, split into the three bf16 terms
     {
-        const bool al = ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+        const bool al = uniform_flag((W & 3) == 0 && ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0);
         const int cg_n = lo.CG, nqR = nRw >> 2, nqL = SW >> 2;
         const int nR_items = cg_n * nqR, n_items = nR_items + cg_n * nqL;
 #pragma unroll 1
@@ -441,27 +496,37 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = pre[c];
             } else {
+#if DECNET_ABLATE == 11     // timing-only: the second half pass without its memory round trip
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    v[c] = 8 * g + c < C ? load4(src + (size_t)(8 * g + c) * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = 0; c < 8; ++c) v[c] = make_float4(1.f * it, 2.f, 3.f, 4.f);
+#else
+                dense16_loads8(v, src, plane, g, C, x, W, al);
+#endif
             }
-            int *dst = (isL ? LT : RT) + (g * (isL ? SW : nRw) + 4 * jq) * 4;
-            const int tstride = cg_n * (isL ? SW : nRw) * 4;              // words between terms
+            const int P = isL ? PL : PR;
+            int *dst = (isL ? LT : RT) + (g * 4 * P + jq) * 4;
+            const int tstride = cg_n * 16 * P;                            // words between terms
 #pragma unroll
             for (int pz = 0; pz < 4; ++pz) {
                 float xv[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) xv[c] = pz == 0 ? v[c].x : pz == 1 ? v[c].y : pz == 2 ? v[c].z : v[c].w;
                 i32x4 th, tm, tl;
+#if DECNET_ABLATE == 12     // timing-only: staging without the bf16 term split
+                th = i32x4{__float_as_int(xv[0]), __float_as_int(xv[1]), __float_as_int(xv[2]), __float_as_int(xv[3])};
+                tm = i32x4{__float_as_int(xv[4]), __float_as_int(xv[5]), __float_as_int(xv[6]), __float_as_int(xv[7])};
+                tl = th;
+#else
                 split3x8(xv, th, tm, tl);
-                *reinterpret_cast<i32x4 *>(dst + pz * 4) = th;
-                *reinterpret_cast<i32x4 *>(dst + tstride + pz * 4) = tm;
-                *reinterpret_cast<i32x4 *>(dst + 2 * tstride + pz * 4) = tl;
+#endif
+                *reinterpret_cast<i32x4 *>(dst + pz * 4 * P) = th;
+                *reinterpret_cast<i32x4 *>(dst + tstride + pz * 4 * P) = tm;
+                *reinterpret_cast<i32x4 *>(dst + 2 * tstride + pz * 4 * P) = tl;
             }
         }
     }
     __syncthreads();
-#if DECNET_ABLATE == 7      // timing-only: masks + both staging phases of a dense row, no cost tiles, no softmax
+#if DECNET_ABLATE == 7 || DECNET_ABLATE == 10 || DECNET_ABLATE == 11 || DECNET_ABLATE == 12     // timing-only: masks + both (10: the first) staging phases of a dense row, no cost tiles, no softmax
     return;
 #endif
 
@@ -473,7 +538,7 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
     // small {lo,hi,lo,mid}
     const int tA_big = q >> 1, tA_small = q == 0 ? 0 : q == 2 ? 1 : 2;
     const int tB_big = q & 1, tB_small = q == 1 ? 0 : q == 3 ? 1 : 2;
-    const int gsR = nRw * 4, gsL = SW * 4;                               // words between channel groups
+    const int gsR = 16 * PR, gsL = 16 * PL;                              // words between channel groups
     for (int xt = wave; xt < XT; xt += NWAVE) {
         const int x0 = xs + xt * 16;
         if (x0 >= W) break;
@@ -499,11 +564,15 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
             acc[m] = f32x4{bz.x, bz.y, bz.z, bz.w};
         }
         // tile m holds right pixels x0 - 16 m + (0..15); the lowest tile (m = NT-1) is the base address
-        const int *a_small = RT + (tA_small * cg_n * nRw + xt * 16 + j) * 4;
-        const int *a_big = RT + (tA_big * cg_n * nRw + xt * 16 + j) * 4;
-        const int *b_small = LT + (tB_small * cg_n * SW + xt * 16 + j) * 4;
-        const int *b_big = LT + (tB_big * cg_n * SW + xt * 16 + j) * 4;
+        const int sa = (j & 3) * PR + 4 * xt + (j >> 2), sb = (j & 3) * PL + 4 * xt + (j >> 2);   // this lane's slots
+        const int *a_small = RT + (tA_small * cg_n * 4 * PR + sa) * 4;
+        const int *a_big = RT + (tA_big * cg_n * 4 * PR + sa) * 4;
+        const int *b_small = LT + (tB_small * cg_n * 4 * PL + sb) * 4;
+        const int *b_big = LT + (tB_big * cg_n * 4 * PL + sb) * 4;
 #if !(DECNET_ABLATE & 1)
+        // (round 5: an explicit software pipeline of this section -- operand reads 3 / 4 / 6 MFMAs ahead, the bias read of
+        // a tile two MFMAs ahead of its first MFMA, pinned with sched_barrier -- measured 0.385 - 0.39 ms against 0.385 - 0.39:
+        // the compiler's one-read-ahead order is not what the pass waits for; profiles/r05z2_*)
 #pragma unroll
         for (int g = 0; g < CGB; ++g) {
             for (int gg = g; gg < cg_n; gg += CGB) {                     // CGT > 0: exactly one trip
@@ -511,13 +580,13 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
                 const i32x4 bb = *reinterpret_cast<const i32x4 *>(b_big + gg * gsL);
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
-                    const i32x4 av = *reinterpret_cast<const i32x4 *>(a_small + gg * gsR + (NT - 1 - m) * 64);
+                    const i32x4 av = *reinterpret_cast<const i32x4 *>(a_small + gg * gsR + (NT - 1 - m) * 16);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
                                                                      __builtin_bit_cast(bf16x8, bs), acc[m], 0, 0, 0);
                 }
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
-                    const i32x4 av = *reinterpret_cast<const i32x4 *>(a_big + gg * gsR + (NT - 1 - m) * 64);
+                    const i32x4 av = *reinterpret_cast<const i32x4 *>(a_big + gg * gsR + (NT - 1 - m) * 16);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
                                                                      __builtin_bit_cast(bf16x8, bb), acc[m], 0, 0, 0);
                 }
@@ -570,6 +639,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const float mark = marker ? sum_sim[(size_t)row * W + (size_t)seg * (XT * 16)] : -1.0f;
     if (marker && !(mark < 0.f))
         return;
+#if DECNET_ABLATE == 8      // timing-only: launch + marker round trip
+    return;
+#endif
     if constexpr (KQ == 2) {
         // marker == 2 (whole rows per workgroup): a row the sparse-row kernel handed over may still have <= 512 active
         // pixels per side (densities 0.25-0.5 at stage 3) -- this workgroup runs the same sparse-row algorithm on it,
@@ -621,7 +693,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
     // fp32 layouts (stages 1, 2): the first pass of the R staging and the left operand of this wave's first tile are
     // requested BEFORE the mask phase -- neither depends on it -- so that a dense row pays one memory round trip where it
     // paid three (masks, then R, then, behind the barrier, the left operand)
-    const bool al_r = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+    const bool al_r = (W & 3) == 0 && ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
     const int st_nq = nRw >> 2;                      // 16-byte groups per channel row of the staged window (<= THREADS)
     const int st_rpp = THREADS / st_nq;              // channel rows per pass
     const int st_r0 = tid / st_nq, st_jq = tid - st_r0 * st_nq;
@@ -633,7 +705,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = st_r0 + u * st_rpp;
-                st_v[u] = c < C ? load4(rrow + (size_t)c * plane, x, W, al_r) : make_float4(0.f, 0.f, 0.f, 0.f);
+                st_v[u] = c < C ? load4_lanes(rrow + (size_t)c * plane, x, W, al_r) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if constexpr (KQ > 0) {
@@ -649,7 +721,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const int p4 = tid * 4;                          // this thread's 4 positions (RP, SW <= 2048)
     int fr = 0, fl = 0;                              // 4 right / left activity bits
     {
-        const bool alm = (((uintptr_t)trow) & 15) == 0 && (((uintptr_t)mrow) & 15) == 0;
+        const bool alm = (W & 3) == 0 && (((uintptr_t)trow) & 15) == 0 && (((uintptr_t)mrow) & 15) == 0;
+        const bool almu = D16 && uniform_flag(alm);     // (dense16 kernels: branch-free, see load4f; the others measured no
+                                                        // gain at stage 2 and lost two workgroups per CU at stage 1: 135 registers)
         if (p4 < nRw) {
             const int x = xs - HALO + p4;
             if (mbits == 2) {
@@ -657,7 +731,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
             } else if (mbits) {
                 fr = mask4_bits(tbits, x, W);
             } else {
-                float4 tv = load4(trow, x, W, alm);
+                float4 tv = almu ? load4f(trow, trow, x, W, true) : load4_lanes(trow, x, W, alm);
                 fr = (tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3);
             }
             float4 bv4;
@@ -674,7 +748,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
                                 : mask4_bits(lbits, xs + p4, W);
                 mv = make_float4((fl & 1) ? 1.f : 0.f, (fl & 2) ? 1.f : 0.f, (fl & 4) ? 1.f : 0.f, (fl & 8) ? 1.f : 0.f);
             } else {
-                mv = load4(mrow, xs + p4, W, alm);
+                mv = almu ? load4f(mrow, mrow, xs + p4, W, true) : load4_lanes(mrow, xs + p4, W, alm);
                 fl = (mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3);
             }
             *reinterpret_cast<float4 *>(LM + p4) = mv;
@@ -695,6 +769,10 @@ __device__ __forceinline__ void spamat_fwd_segment(
         const int validL = min(SW, W - xs);
         const int validR = min(W, xs + SW) - max(0, xs - HALO);
         compact = allow_compact && ((long)nL * nR * 100 < (long)validL * validR * compact_pct);
+#if DECNET_ABLATE == 9      // timing-only: + first-half loads requested, mask phase, counts
+        if (tid == 0 && d16_pre[0].x == 1.2345f) out[0] = 0.f;
+        return;
+#endif
         if (!compact) {
             // two passes over half the segment each: both views as bf16 terms need 96 bytes of LDS per pixel and
             // channel group, and the segment partition (= the number of workgroups of a marker launch, the
@@ -703,7 +781,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
             dense16_body<NT, MODE, (KQ + 1) / 2, true>(reinterpret_cast<int *>(Rs), BX, LM, smem, lrow, rrow, disparity, out,
                                                        var_out, sum_sim, max_cost, plane, rowpix, C, W, D, xs, xta, xta * 16,
                                                        HALO, HALO + xta * 16, d16_pre);
-            if (xtb > 0 && xs + xta * 16 < W) {
+            if (DECNET_ABLATE != 10 && xtb > 0 && xs + xta * 16 < W) {
                 __syncthreads();
                 dense16_body<NT, MODE, (KQ + 1) / 2>(reinterpret_cast<int *>(Rs), BX + xta * 16, LM + xta * 16, smem, lrow,
                                                      rrow, disparity, out, var_out, sum_sim, max_cost, plane, rowpix, C,
@@ -731,7 +809,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int c = c0 + u * rpp;
-                        v[u] = c < C ? load4(rrow + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[u] = c < C ? load4_lanes(rrow + (size_t)c * plane, x, W, al) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
 #pragma unroll
@@ -1087,12 +1165,14 @@ __device__ __forceinline__ int sparse_row_body(
     const int p4 = tid * PPT;                        // this thread's PPT consecutive pixels
     float4 lv[ALL ? CQ : 1], rv[ALL ? CQ : 1];
     if constexpr (ALL) {
+        // (load4_lanes: here the per-lane form compiles to sixteen requests in flight -- checked in the ISA -- and the
+        // branch-free form measured 2 - 4 % slower at densities 0.3 - 0.4)
         const bool alf = ((W & 3) == 0) && ((((uintptr_t)lrow) | ((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
 #pragma unroll
         for (int c = 0; c < CQ; ++c) {
             const bool ok = p4 < W && c < C;
-            lv[c] = ok ? load4(lrow + (size_t)c * plane, p4, W, alf) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rv[c] = ok ? load4(rrow + (size_t)c * plane, p4, W, alf) : make_float4(0.f, 0.f, 0.f, 0.f);
+            lv[c] = ok ? load4_lanes(lrow + (size_t)c * plane, p4, W, alf) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[c] = ok ? load4_lanes(rrow + (size_t)c * plane, p4, W, alf) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     // ---- 1. masks -> bits, counts
@@ -1111,7 +1191,7 @@ __device__ __forceinline__ int sparse_row_body(
                     fr |= mask4_bits(reinterpret_cast<const unsigned long long *>(tmask) + (size_t)row * wpr, p4 + u, W) << u;
                     fl |= mask4_bits(reinterpret_cast<const unsigned long long *>(rmask) + (size_t)row * wpr, p4 + u, W) << u;
                 } else {
-                    const float4 tv = load4(trow, p4 + u, W, alm), mv = load4(mrow, p4 + u, W, alm);
+                    const float4 tv = load4_lanes(trow, p4 + u, W, alm), mv = load4_lanes(mrow, p4 + u, W, alm);
                     fr |= ((tv.x != 0.f) | ((tv.y != 0.f) << 1) | ((tv.z != 0.f) << 2) | ((tv.w != 0.f) << 3)) << u;
                     fl |= ((mv.x != 0.f) | ((mv.y != 0.f) << 1) | ((mv.z != 0.f) << 2) | ((mv.w != 0.f) << 3)) << u;
                 }

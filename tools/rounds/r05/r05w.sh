@@ -1,0 +1,14 @@
+#!/bin/bash
+# stages 1 - 2 forward: the library before (tools/ubench/libdecnet_dev_oldfull.so) vs the working tree's library
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05w; mkdir -p $O
+cd $R
+for rep in 1 2 3; do
+  for t in old new; do
+    if [ $t = old ]; then export DECNET_HIP_LIB=$R/tools/ubench/libdecnet_dev_oldfull.so; else unset DECNET_HIP_LIB; fi
+    for s in 1 2; do for d in 1.0 0.3; do echo -n "$t " >> $O/times.txt; python3 tools/bench_spamat.py --stage $s --density $d --iters 50 2>/dev/null >> $O/times.txt; done; done
+    echo -n "$t " >> $O/times.txt; python3 tools/bench_spamat.py --stage 3 --density 1.0 --iters 40 2>/dev/null >> $O/times.txt
+  done
+done
+unset DECNET_HIP_LIB
+timeout 1200 python3 -m pytest tests/test_spamat_gpu.py tests/test_spamat_ref.py -m gpu -q 2>&1 | tail -3 >> $O/times.txt
+cat $O/times.txt | sed 's/algorithmic //'
