@@ -689,12 +689,24 @@ __global__ __launch_bounds__(256) void cout1_gather_softargmax(const float *__re
     if (pl < PB && pix < npix) {
         const int xx = pix % W, t = pix / W;
         const int yy = t % H, b = t / H;
+        // all 27 requests before the first use (round 5, from the ISA: `if (inside) acc += T[..]` was 27 serial round
+        // trips: a load under a per-lane branch, waited for at once); taps outside the volume read the centre's entry and
+        // add 0 -- the same sum in the same order
+        float tv[27];
+        const size_t centre = ((((size_t)b * D + d) * H + yy) * W + xx) * 32;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int zd = d + tap / 9 - 1, zy = yy + (tap / 3) % 3 - 1, zx = xx + tap % 3 - 1;
+            const bool ok = (unsigned)zd < (unsigned)D && (unsigned)zy < (unsigned)H && (unsigned)zx < (unsigned)W;
+            tv[tap] = T[ok ? ((((size_t)b * D + zd) * H + zy) * W + zx) * 32 + tap : centre + tap];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         float acc = 0.f;
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int zd = d + tap / 9 - 1, zy = yy + (tap / 3) % 3 - 1, zx = xx + tap % 3 - 1;
-            if ((unsigned)zd < (unsigned)D && (unsigned)zy < (unsigned)H && (unsigned)zx < (unsigned)W)
-                acc += T[((((size_t)b * D + zd) * H + zy) * W + zx) * 32 + tap];
+            const bool ok = (unsigned)zd < (unsigned)D && (unsigned)zy < (unsigned)H && (unsigned)zx < (unsigned)W;
+            acc += ok ? tv[tap] : 0.f;
         }
         const float cost = fmaf(acc, scale, shift);
         costs[pl * D + d] = cost;

@@ -57,20 +57,31 @@ __global__ __launch_bounds__(256) void tap_gather(const float *__restrict__ M, c
     const int p0 = blockIdx.x * 64, cg = blockIdx.y, ib = blockIdx.z;
     const int co_lo = threadIdx.x & 15, pq = threadIdx.x >> 4;        // 16 positions per pass
     const int kk = br.kk[ib], dil = br.dil[ib], k = kk == 9 ? 3 : 1;
+    // all of a thread's requests (4 positions x up to 9 taps) before the first use -- round 5, from the ISA: `if (inside)
+    // acc += M[..]` was one memory round trip per tap and pass, 36 in a row.  A tap outside the image (or past kk, or a
+    // position past P) reads the position's own entry of the branch's first tap and adds 0: same sum, same order.
+    float tv[4][9];
+    bool ok[4][9];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-        const int pl = pass * 16 + pq, p = p0 + pl;
-        float acc = 0.f;
-        if (p < P) {
-            const int b = p / HW, i = p - b * HW, yy = i / W, xx = i - yy * W;
-            for (int t = 0; t < kk; ++t) {
-                const int dy = (t / k - k / 2) * dil, dx = (t % k - k / 2) * dil;
-                const int y2 = yy + dy, x2 = xx + dx;
-                if ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
-                    acc += M[(((size_t)(br.tap0[ib] + t) * CG + cg) * P + (p + dy * W + dx)) * 16 + co_lo];
-            }
+        const int pl = pass * 16 + pq, p = p0 + pl, pc = p < P ? p : P - 1;
+        const int b = pc / HW, i = pc - b * HW, yy = i / W, xx = i - yy * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = (t / k - k / 2) * dil, dx = (t % k - k / 2) * dil;
+            const int y2 = yy + dy, x2 = xx + dx;
+            ok[pass][t] = t < kk && p < P && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W;
+            tv[pass][t] = ok[pass][t] ? M[(((size_t)(br.tap0[ib] + t) * CG + cg) * P + (pc + dy * W + dx)) * 16 + co_lo]
+                                      : 0.f;
         }
-        tile[co_lo][pl] = acc;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += ok[pass][t] ? tv[pass][t] : 0.f;
+        tile[co_lo][pass * 16 + pq] = acc;
     }
     __syncthreads();
     const int co = cg * 16 + (threadIdx.x >> 4);

@@ -17,13 +17,14 @@ __global__ __launch_bounds__(256) void unfold3_cat(const float *__restrict__ fea
         return;
     }
     const float *f = fea + (((size_t)b * C + c) * 3 * h + 3 * y) * (3 * (size_t)w) + 3 * x;
+    float v[9];                                     // nine requests, then nine stores
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float v0 = f[(size_t)i * 3 * w], v1 = f[(size_t)i * 3 * w + 1], v2 = f[(size_t)i * 3 * w + 2];
-        o[(size_t)(1 + c * 9 + i * 3 + 0) * cp] = v0;
-        o[(size_t)(1 + c * 9 + i * 3 + 1) * cp] = v1;
-        o[(size_t)(1 + c * 9 + i * 3 + 2) * cp] = v2;
-    }
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[i * 3 + j] = f[(size_t)i * 3 * w + j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[(size_t)(1 + c * 9 + t) * cp] = v[t];
 }
 // The stride-3 convolutions of FeatExtNetChannelPlus (Conv2d k 3, stride 3, padding 1: submodule.py:270-300) as a
 // space-to-depth gather in front of a 1 x 1 convolution on the matrix cores (csrc/conv2d_mfma.hip):
@@ -38,17 +39,19 @@ __global__ __launch_bounds__(256) void s2d3_pad1(const float *__restrict__ x, fl
     const size_t cp = (size_t)Ho * Wo;
     float *o = out + ((size_t)b * 9 * C + 9 * c) * cp + (size_t)yo * Wo + xo;
     const float *f = x + ((size_t)b * C + c) * H * (size_t)W;
-#pragma unroll
+    float v[9];                                     // nine requests, then nine stores (a store right behind its load
+#pragma unroll                                      // is a memory round trip per tap: round 5, from the ISA)
     for (int ky = 0; ky < 3; ++ky) {
         const int yi = 3 * yo - 1 + ky;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int xi = 3 * xo - 1 + kx;
-            float v = 0.f;
-            if (yi >= 0 && yi < H && xi >= 0 && xi < W) v = f[(size_t)yi * W + xi];
-            o[(size_t)(ky * 3 + kx) * cp] = v;
+            v[ky * 3 + kx] = (yi >= 0 && yi < H && xi >= 0 && xi < W) ? f[(size_t)yi * W + xi] : 0.f;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[(size_t)t * cp] = v[t];
 }
 }  // namespace
 
