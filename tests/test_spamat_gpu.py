@@ -475,3 +475,40 @@ def test_graphed_step_replays_forward_and_backward(dev):
         a, b = it[0].detach().clone().requires_grad_(), it[1].detach().clone().requires_grad_()
         mod(a, b, it[2], it[3], it[4]).backward(it[5])
         assert torch.equal(a.grad, gl) and torch.equal(b.grad, gr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,W,D,p", [(7, 972, 216, 1.0), (5, 640, 216, 1.0), (6, 326, 216, 0.9), (8, 970, 216, 1.0),
+                                     (8, 972, 216, 1.0), (8, 648, 100, 1.0)])
+def test_dense_rows_batched_staging_loads(dev, C, W, D, p):
+    """Round 5: a dense row's staging item is ONE batch of raw 16-byte loads behind a workgroup-uniform flag (rows on
+    16-byte boundaries, W % 4 == 0) and four guarded loads otherwise.  Both forms, partial channel groups (C = 5 .. 7:
+    the missing channels must read as zeros), rows whose left edge lies inside the first halo, against the oracle; H = 3
+    rows so that W % 4 != 0 gives rows of every alignment."""
+    import decnet_amd
+    B, H = 1, 3
+    L, R, rm, tm = make_case(31 + C, B, C, H, W, p, p)
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    outs = decnet_amd.spamatvar_forward(L.to(dev), R.to(dev), rm.to(dev), tm.to(dev), D)
+    check_fwd(o, s, m, outs[0], outs[2], outs[3], D)
+    v, _, _ = oracle.spavar_forward(L, R, rm, tm, o, D)
+    np.testing.assert_allclose(outs[1].cpu().numpy(), v, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,W,D", [(24, 324, 72), (24, 322, 72), (72, 108, 24), (72, 106, 24), (20, 200, 72)])
+def test_backward_band_kernel_batched_loads(dev, C, W, D):
+    """The backward band kernel's staging (features, mask, per-pixel planes) as batches of raw loads on aligned rows and
+    as guarded loads on ragged ones (W % 4 != 0: rows of every alignment), C below the staged channel count (20 of 24)."""
+    import decnet_amd
+    B, H = 1, 3
+    L, R, rm, tm = make_case(41, B, C, H, W, 0.9, 0.9, relu=False, scale=0.5)
+    g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(6))
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    gl, gr = oracle.spamat_backward(L, R, rm, tm, o, s, m, g, D)
+    dL, dR = L.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+    out = decnet_amd.SpaMatFunction.apply(dL, dR, rm.to(dev), tm.to(dev), D)
+    out.backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 2e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 2e-5 * sc
