@@ -40,7 +40,11 @@
 
 #ifndef DECNET_ABLATE
 #define DECNET_ABLATE 0   // 1: skip MFMAs, 2: skip softmax passes, 3: both (diagnostic builds only,
-#endif                    // tools/ablate.sh; results are wrong by construction)
+#endif                    // tools/ablate.sh, tools/dev_spamat.sh; results are wrong by construction);
+                          // 5: fp32 layouts, masks + R staging only; 6: sparse-row bodies without the matching;
+                          // dense stage-3 rows, leaving the band kernel earlier and earlier: 8 launch + marker, 9 + mask
+                          // phase, 10 + first half pass's staging, 7 + second half's; 11 = 7 without the second half's
+                          // loads, 12 = 7 without the bf16 term split (docs/rounds/r05.md)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
