@@ -688,6 +688,17 @@ __device__ __forceinline__ void spamat_fwd_segment(
 
     // bf16 layout (stage 3 dense rows): the loads of this thread's first staging item of the first half pass, requested
     // before the mask phase too (a compact row wastes them)
+    // dense16 kernels: the handed-over activity words are requested BEFORE the first half pass's features (loads return in
+    // order: behind the features the mask phase would wait for all of them; - 1.3 % on dense rows, profiles/r05z2_*)
+    unsigned mf_wr = 0, mf_wl = 0;
+    if constexpr (D16) {
+        if (mbits == 2) {
+            const int q4 = tid * 4, xr_ = xs - HALO + q4, xl_ = xs + q4;
+            const unsigned *hw = reinterpret_cast<const unsigned *>(max_cost + rowpix);
+            mf_wr = hw[(q4 < nRw && xr_ >= 0 && xr_ < W) ? xr_ >> 5 : 0];
+            mf_wl = hw[((W + 31) >> 5) + ((q4 < SW && xl_ < W) ? xl_ >> 5 : 0)];
+        }
+    }
     float4 d16_pre[D16 ? 8 : 1];
     if constexpr (D16) {
         const int xta = (XT + 1) / 2;
@@ -731,7 +742,8 @@ __device__ __forceinline__ void spamat_fwd_segment(
         if (p4 < nRw) {
             const int x = xs - HALO + p4;
             if (mbits == 2) {
-                fr = mask4_words(reinterpret_cast<const unsigned *>(max_cost + rowpix), x, W);
+                if (D16) fr = (x >= 0 && x < W) ? (int)((mf_wr >> (x & 31)) & 15u) : 0;
+                else fr = mask4_words(reinterpret_cast<const unsigned *>(max_cost + rowpix), x, W);
             } else if (mbits) {
                 fr = mask4_bits(tbits, x, W);
             } else {
@@ -748,7 +760,8 @@ __device__ __forceinline__ void spamat_fwd_segment(
         if (p4 < SW) {
             float4 mv;
             if (mbits) {
-                fl = mbits == 2 ? mask4_words(reinterpret_cast<const unsigned *>(max_cost + rowpix) + ((W + 31) >> 5), xs + p4, W)
+                if (D16 && mbits == 2) fl = (xs + p4 < W) ? (int)((mf_wl >> ((xs + p4) & 31)) & 15u) : 0;
+                else fl = mbits == 2 ? mask4_words(reinterpret_cast<const unsigned *>(max_cost + rowpix) + ((W + 31) >> 5), xs + p4, W)
                                 : mask4_bits(lbits, xs + p4, W);
                 mv = make_float4((fl & 1) ? 1.f : 0.f, (fl & 2) ? 1.f : 0.f, (fl & 4) ? 1.f : 0.f, (fl & 8) ? 1.f : 0.f);
             } else {
