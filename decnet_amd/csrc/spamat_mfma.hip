@@ -62,8 +62,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // 4 consecutive floats row[x .. x+3], zeros outside [0, W); one 16-byte load when possible.
 // Four consecutive values row[x .. x + 3] (zeros outside [0, W)), x a multiple of 4, in two forms chosen by a
-// WORKGROUP-UNIFORM flag `al` (uniform_flag(): the rows start on 16-byte boundaries and W is a multiple of 4, so a group
-// lies inside or outside its row as a whole):
+// WORKGROUP-UNIFORM flag `al` (uniform_flag(): the rows start on 16-byte boundaries; with W a multiple of 4 a group lies
+// inside or outside its row as a whole, otherwise the caller does the row's last group with load4s after its batch):
 //   load4f  ONE unconditional 16-byte load -- lanes that are outside (or whose channel does not exist: `ok`) read `safe`,
 //           any aligned readable address -- and a select (SEL = false: no select; for callers whose outside lanes are
 //           finite-but-ignored: right pixels outside the row carry the -1e30 bias, left pixels outside it are not stored);
@@ -439,8 +439,10 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
 __device__ __forceinline__ void dense16_loads8(float4 (&v)[8], const float *__restrict__ src, size_t plane, int g, int C,
                                                int x, int W, bool al) {
     if (al) {
+        const bool whole = x + 3 < W;                   // W % 4 != 0: the row's last group is done after the batch
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = load4f<false>(src, src + (size_t)(8 * g + c) * plane, x, W, 8 * g + c < C);
+        for (int c = 0; c < 8; ++c)
+            v[c] = load4f<false>(src, src + (size_t)(8 * g + c) * plane, x, W, whole && 8 * g + c < C);
         __builtin_amdgcn_sched_barrier(0);              // all eight requests before anything that waits for one
         if (C & 7) {                                    // (uniform) a partial channel group: its missing channels are zeros
 #pragma unroll
@@ -448,6 +450,11 @@ __device__ __forceinline__ void dense16_loads8(float4 (&v)[8], const float *__re
                 const bool ch = 8 * g + c < C;
                 v[c] = make_float4(ch ? v[c].x : 0.f, ch ? v[c].y : 0.f, ch ? v[c].z : 0.f, ch ? v[c].w : 0.f);
             }
+        }
+        if ((W & 3) && x < W && !whole) {               // (W & 3: uniform) one group per row: guarded loads
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                v[c] = 8 * g + c < C ? load4s(src + (size_t)(8 * g + c) * plane, x, W) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
 #pragma unroll
@@ -460,7 +467,7 @@ __device__ __forceinline__ void dense16_loads8(float4 (&v)[8], const float *__re
 __device__ __forceinline__ void dense16_item_loads(float4 (&v)[8], int it, const float *__restrict__ lrow,
                                                    const float *__restrict__ rrow, size_t plane, int C, int W, int xs,
                                                    int SW, int HALO, int nRw) {
-    const bool al = uniform_flag((W & 3) == 0 && ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0);
+    const bool al = uniform_flag(((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0);
     const int cg_n = (C + 7) >> 3, nqR = nRw >> 2, nqL = SW >> 2;
     const int nR_items = cg_n * nqR;
     const bool isL = it >= nR_items;
@@ -485,7 +492,7 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
     int *LT = RT + 3 * lo.CG * 16 * PR;
     // ---- features of both views: 8 channels x 4 positions per item, split into the three bf16 terms
     {
-        const bool al = uniform_flag((W & 3) == 0 && ((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0);
+        const bool al = uniform_flag(((((uintptr_t)rrow) | ((uintptr_t)lrow) | ((uintptr_t)(plane * 4))) & 15) == 0);
         const int cg_n = lo.CG, nqR = nRw >> 2, nqL = SW >> 2;
         const int nR_items = cg_n * nqR, n_items = nR_items + cg_n * nqL;
 #pragma unroll 1
@@ -708,7 +715,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
     // fp32 layouts (stages 1, 2): the first pass of the R staging and the left operand of this wave's first tile are
     // requested BEFORE the mask phase -- neither depends on it -- so that a dense row pays one memory round trip where it
     // paid three (masks, then R, then, behind the barrier, the left operand)
-    const bool al_r = (W & 3) == 0 && ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
+    const bool al_r = ((((uintptr_t)rrow) | ((uintptr_t)(plane * 4))) & 15) == 0;
     const int st_nq = nRw >> 2;                      // 16-byte groups per channel row of the staged window (<= THREADS)
     const int st_rpp = THREADS / st_nq;              // channel rows per pass
     const int st_r0 = tid / st_nq, st_jq = tid - st_r0 * st_nq;
@@ -736,8 +743,8 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const int p4 = tid * 4;                          // this thread's 4 positions (RP, SW <= 2048)
     int fr = 0, fl = 0;                              // 4 right / left activity bits
     {
-        const bool alm = (W & 3) == 0 && (((uintptr_t)trow) & 15) == 0 && (((uintptr_t)mrow) & 15) == 0;
-        const bool almu = D16 && uniform_flag(alm);     // (dense16 kernels: branch-free, see load4f; the others measured no
+        const bool alm = (((uintptr_t)trow) & 15) == 0 && (((uintptr_t)mrow) & 15) == 0;
+        const bool almu = D16 && uniform_flag(alm && (W & 3) == 0);     // (dense16 kernels: branch-free, see load4f; the others measured no
                                                         // gain at stage 2 and lost two workgroups per CU at stage 1: 135 registers)
         if (p4 < nRw) {
             const int x = xs - HALO + p4;
