@@ -1585,6 +1585,10 @@ int launch_kq(int mode, const float *ref, const float *tar, const float *rmask, 
 #define GO(K)                                                                                      \
     return launch_nt<NT, K>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,        \
                             max_cost, B, C, H, W, D, allow_compact, mbits, stream)
+#ifdef DECNET_DEV_STAGE2               // experiment builds: the stage-2 instantiation only
+    if (C <= 24 && C > 20) GO(6);
+    return DECNET_ERR_UNSUPPORTED;
+#endif
     if (C <= 8 && C > 4) GO(2);        // stage 3 of the shipped network (C = 8)
 #ifdef DECNET_DEV_STAGE3               // tools/dev_spamat.sh: the stage-3 instantiation only (seconds to compile)
     return DECNET_ERR_UNSUPPORTED;
@@ -1612,6 +1616,10 @@ int decnet_mfma_forward(int mode, const float *ref, const float *tar, const floa
 #define GO(N)                                                                                     \
     return launch_kq<N>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, \
                         B, C, H, W, D, allow_compact, mbits, stream)
+#ifdef DECNET_DEV_STAGE2        // experiment builds: the stage-2 instantiation only
+    if (need <= 6 && need > 3) GO(6);
+    return DECNET_ERR_UNSUPPORTED;
+#endif
 #ifdef DECNET_DEV_STAGE3        // tools/dev_spamat.sh: the stage-3 instantiation only
     if (need <= 15 && need > 11) GO(15);
     return DECNET_ERR_UNSUPPORTED;
