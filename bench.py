@@ -347,7 +347,7 @@ def live_traffic(config):
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--config", str(config), "--steps", "3", "--warmup", "1",
                    "--no-cpu-baseline", "--no-e2e", "--no-train", "--no-density-sweep", "--no-alt", "--no-valu-floor",
-                   "--no-live-traffic"]
+                   "--no-live-traffic", "--no-blocks"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
@@ -376,7 +376,7 @@ def alt_gemm_leg():
     import subprocess
     env = dict(os.environ, DECNET_WINO_GEMM="fp32")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "50", "--warmup", "8", "--no-cpu-baseline", "--no-train",
-           "--no-density-sweep", "--no-e2e", "--no-alt", "--no-live-traffic", "--no-valu-floor"]
+           "--no-density-sweep", "--no-e2e", "--no-alt", "--no-live-traffic", "--no-valu-floor", "--no-blocks"]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -472,19 +472,18 @@ E2E_FAMILIES = (
     ("wino_", "stage 0: other Winograd transforms"),
     ("cout1_", "stage 0: Conv3d 216->1 + soft-argmax"),
     ("spamat_fwd", "cost-volume pass: fused SpaMat + SpaVar, stages 1-3"),
-    ("deconv2d_mfma", "2-D trunk: many-channel transposed convolutions [bf16x3]"),
     ("conv2d_mfma", "2-D trunk: many-channel 3x3 / 1x1 convolutions [bf16x3 on the bf16 matrix pipe]"),
     ("conv2d_f32m", "2-D trunk: few-channel 3x3 convolutions [fp32, v_mfma_f32_4x4x1]"),
     ("conv2d_small", "2-D trunk: few-channel convolutions [fp32 FMA]"),
+    ("deconv2d_k3s3", "2-D trunk: stride-3 few-channel transposed convolutions"),     # before its substring "conv2d_k3s3"
     ("conv2d_k3s3", "2-D trunk: stride-3 few-channel convolutions"),
-    ("deconv2d_k3s3", "2-D trunk: stride-3 few-channel transposed convolutions"),
     ("detail_mask", "mask generator tail (sigmoid > thold, bit-packed masks)"),
     ("warp_disparity", "Refinement: warp of the right features"),
     ("miopen", "library convolutions (MIOpen / Tensile)"), ("Cijk", "library convolutions (MIOpen / Tensile)"),
     ("igemm", "library convolutions (MIOpen / Tensile)"), ("MIOpen", "library convolutions (MIOpen / Tensile)"),
 )
 # Unit kinds (decnet_amd.model._tally) -> the family prefix above
-UNIT_KIND_PREFIX = {"mfma": "conv2d_mfma", "mfma_s3": "conv2d_mfma", "mfma_deconv": "deconv2d_mfma", "conv": "conv2d_small",
+UNIT_KIND_PREFIX = {"mfma": "conv2d_mfma", "mfma_s3": "conv2d_mfma", "mfma_deconv": "conv2d_mfma", "conv": "conv2d_small",
                     "conv_s3": "conv2d_k3s3", "deconv": "deconv2d_k3s3", "library": "miopen"}
 
 
@@ -559,7 +558,7 @@ def e2e_kernel_table(B, unit_work, top=5):
             t = work.setdefault(pre, {"flops": 0.0, "bytes": 0.0})
             t["flops"] = t.get("flops", 0.0) + w["flops"]
             t["bytes"] = t.get("bytes", 0.0) + w["bytes"]
-    for pre in ("conv2d_mfma", "deconv2d_mfma"):
+    for pre in ("conv2d_mfma",):
         if pre in work:
             work[pre].update(executed_x=6.0, peak_tf=MFMA_BF16_PEAK_TF)      # three bf16 terms per operand, six products
     # the few-channel kernels share their layers' report: conv2d_f32m and conv2d_small are two kernels of the "conv" kind
@@ -838,6 +837,67 @@ def timed_region(step, drain, warmup, steps, world, dev):
     return elapsed
 
 
+def value_blocks(step, drain, steps, world, dev, units_per_step, nblocks=5):
+    """The timed region again, `nblocks` times back to back in the same process (each block = exactly `steps` steps
+    between barrier + synchronize, like `value`'s own): min / median / max of the per-block rate, so that a
+    box-to-box or clock difference can be told from a code difference on one run."""
+    vals = []
+    for _ in range(nblocks):
+        el = timed_region(step, drain, 0, steps, world, dev)
+        vals.append(units_per_step * steps / el)
+    sv = sorted(vals)
+    return {"n_blocks": nblocks, "steps_per_block": steps, "min": sv[0], "median": sv[len(sv) // 2], "max": sv[-1],
+            "blocks": vals, "unit": "pairs/s",
+            "note": "the same timed region repeated after `value`'s own; `value` is the FIRST block after the warmup"}
+
+
+def smi_under_load(step, drain, min_s=1.5):
+    """Shader clock and package power WHILE the hot path runs: a rocm-smi child is started, the step loop keeps the GPU
+    busy until the child has exited (rank 0, one GPU; never inside a timed region).  None if rocm-smi is not there."""
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    box = {}
+
+    def run():
+        try:
+            time.sleep(0.4)                              # let the loop below reach its steady state first
+            r = subprocess.run([smi, "-d", str(torch.cuda.current_device()), "--showclocks", "--showpower", "--json"],
+                               capture_output=True, text=True, timeout=30)
+            box["raw"] = r.stdout
+        except Exception as e:                           # noqa: BLE001 -- an extra key, never fatal
+            box["err"] = "%s: %s" % (type(e).__name__, str(e)[:120])
+    th = threading.Thread(target=run)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while th.is_alive() or time.perf_counter() - t0 < min_s:
+        for _ in range(20):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        n += 20
+    th.join()
+    out = {"steps_run_meanwhile": n, "busy_s": time.perf_counter() - t0}
+    try:
+        card = next(iter(json.loads(box["raw"]).values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl:
+                out["sclk"] = v
+            elif "mclk" in kl:
+                out["mclk"] = v
+            elif "power" in kl:
+                out.setdefault("power", {})[k] = v
+    except Exception as e:                               # noqa: BLE001
+        out["error"] = box.get("err") or "%s: %s" % (type(e).__name__, str(e)[:120])
+        out["raw"] = (box.get("raw") or "")[:300]
+    return out
+
+
 def main_train(args, B, dev, world, rank):
     """--config 5 (see TrainShare)."""
     ts = TrainShare(B, dev, args.mask_density, world)
@@ -931,6 +991,9 @@ def main():
     ap.add_argument("--no-e2e-table", action="store_true",
                     help="skip e2e.roofline: the per-kernel-family table of one forward (a child process under "
                          "rocprofv3 --kernel-trace)")
+    ap.add_argument("--no-blocks", action="store_true",
+                    help="skip value_blocks (the timed region repeated 5 more times: min / median / max) and the "
+                         "rocm-smi sample of shader clock and package power under load")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the extra 'e2e' object: the whole inference graph (decnet_amd.model: the 2-D "
                          "trunk around the hot path) timed on the same batch, eager and as a HIP-graph replay")
@@ -986,6 +1049,8 @@ def main():
     with torch.no_grad():
         # nothing but the work inside the timed region (no events); every all-gather has landed when it ends
         elapsed = timed_region(hp.step, hp.drain, args.warmup, args.steps, world, dev)
+        blocks = None if args.no_blocks else value_blocks(hp.step, hp.drain, args.steps, world, dev, world * B)
+        smi = smi_under_load(hp.step, hp.drain) if (rank == 0 and world == 1 and not args.no_blocks) else None
         # per-stage breakdown from a few extra steps with events around stage 0 and stage 3 (an event
         # record costs ~20 us of pipeline bubble each, so they stay out of the timed region)
         nev = min(args.steps, 10)
@@ -1189,6 +1254,10 @@ def main():
                                          "of 8 TB/s (DESIGN.md section 4); the HBM-shaped regime is the sparse one "
                                          "in roofline_costvol_sparse"},
         }
+        if blocks:
+            out["value_blocks"] = blocks
+        if smi:
+            out["smi_under_load"] = smi
         if hp.coll:
             # the step's collective alone (not overlapped), and that what it delivers is what was sent
             with torch.no_grad():
@@ -1212,6 +1281,14 @@ def main():
                 if row["mask_density"] in (0.5, 0.3, 0.1):
                     fad["%.1f" % row["mask_density"]] = s3_bytes / row["ms"] / 1e6 / HBM_PEAK_GBS
             out["roofline_costvol"]["frac_at_density"] = fad
+            # ... and inside `roofline`, the object the driver's record keeps: the cost-volume pass (stage 3, fused
+            # SpaMat + SpaVar) against the HBM roof, beside the dominant kernel's own figures
+            out["roofline"]["costvol_pass"] = {
+                "kernel": "spamat fused fwd, stage 3", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bytes_per_launch": s3_bytes, "frac_at_density": fad,
+                "ms_at_density": dict({"1.0": s3_ms}, **{"%.1f" % r_["mask_density"]: r_["ms"] for r_ in by_density
+                                                          if r_["mask_density"] in (0.5, 0.3, 0.1)}),
+                "valu_floor_frac_dense": valu["frac"] if valu else None}
             out["roofline_costvol"]["ms_at_density"] = dict({"1.0": s3_ms}, **{
                 "%.1f" % r_["mask_density"]: r_["ms"] for r_ in by_density if r_["mask_density"] in (0.5, 0.3, 0.1)})
         if world == 1 and not args.no_train and args.config == 2:

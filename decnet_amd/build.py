@@ -110,7 +110,17 @@ def build_pybind(force=False, verbose=False):
     inc = ["-I" + os.path.join(troot, "include"), "-I" + os.path.join(troot, "include", "torch", "csrc", "api", "include"),
            "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include",
            "-I" + os.path.join(os.path.dirname(HERE), "include")]
-    defs = ["-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2", "-DTORCH_API_INCLUDE_EXTENSION_H"]
+    defs = ["-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2", "-DTORCH_API_INCLUDE_EXTENSION_H",
+            # the libstdc++ string ABI torch itself was built with (the other one links, then fails at import with
+            # undefined c10 symbols)
+            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    stamp = os.path.join(PYBIND_SRC, ".built_for")             # torch version + ABI the modules were compiled against
+    want = "%s abi%d" % (torch.__version__, int(torch._C._GLIBCXX_USE_CXX11_ABI))
+    try:
+        with open(stamp) as f:
+            force = force or f.read().strip() != want
+    except OSError:
+        force = True
     cxx = os.environ.get("CXX", "g++")
     deps = [os.path.join(PYBIND_SRC, "torch_boundary.h"), os.path.join(os.path.dirname(HERE), "include", "decnet_hip.h")]
     procs, outs = [], []
@@ -133,6 +143,8 @@ def build_pybind(force=False, verbose=False):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
         os.replace(out + ".tmp", out)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return outs
 
 

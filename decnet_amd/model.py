@@ -262,7 +262,16 @@ class Unit(nn.Module):
         """out: write into this [B,Cout,H,W] buffer (kind "conv"); epi / ea / eb: decnet_conv2d_cat_epilogue's fused tail
         of a single-output layer; neg_last: see _folded."""
         if TALLY is not None:
+            n_tally = len(TALLY)
             _tally(self, kind, x)
+            try:
+                return self._forward_hip_kind(x, kind, out, epi, ea, eb, neg_last)
+            except DecnetHipError:                       # forward() falls back to the library path and tallies THAT
+                del TALLY[n_tally:]
+                raise
+        return self._forward_hip_kind(x, kind, out, epi, ea, eb, neg_last)
+
+    def _forward_hip_kind(self, x, kind, out, epi, ea, eb, neg_last):
         if kind == "mfma":
             return self._forward_mfma(x)
         if kind == "mfma_deconv":

@@ -31,3 +31,42 @@ def test_gpus_2_starts_two_ranks_itself():
 def test_world_size_mismatch_is_an_error():
     r = _run({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--selftest-cpu")
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_traffic_json_cites_files_that_exist():
+    """profiles/traffic.json names the rocprofv3 summary each average came from: the file must be in the repository
+    (round 5 committed the CSV under another tag than the one the json recorded)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "traffic.json")) as f:
+        tj = json.load(f)
+    cited = set()
+
+    def walk(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if isinstance(v, str) and v.startswith("profiles/") and k.endswith("_source"):
+                    cited.add(v)
+                walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+    walk(tj)
+    assert cited, "traffic.json no longer says where its averages came from"
+    for c in sorted(cited):
+        assert os.path.exists(os.path.join(root, c)), c
+
+
+def test_unit_kinds_resolve_to_their_own_family():
+    """bench.E2E_FAMILIES matches kernel names by substring, first match wins: every family a unit kind is filed under
+    must come out of the matcher as itself (round 5: 'conv2d_k3s3' sat before 'deconv2d_k3s3' and swallowed it)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    fams = [p for p, _ in bench.E2E_FAMILIES]
+    for kind, pre in bench.UNIT_KIND_PREFIX.items():
+        assert pre in fams, (kind, pre)
+        assert next(p for p in fams if p in pre + "<8>") == pre, (kind, pre)
+    assert next(p for p in fams if p in "void (anonymous namespace)::deconv2d_k3s3<8>(float const*") == "deconv2d_k3s3"

@@ -46,6 +46,12 @@ def test_bench_line_contract():
     assert tj["kernel_match"] in r["kernel"]
     if "rocprof_avg_ms" in tj:                          # the committed rocprofv3 --kernel-trace --stats average
         assert abs(r["ms"] - tj["rocprof_avg_ms"]) < 0.2 * tj["rocprof_avg_ms"], (r["ms"], tj["rocprof_avg_ms"])
+    assert os.path.exists(os.path.join(ROOT, tj["rocprof_avg_ms_source"])), tj["rocprof_avg_ms_source"]
+    # the same timed region five more times (spread of one box) and the clock / power it ran at
+    vb = d["value_blocks"]
+    assert vb["n_blocks"] == 5 and len(vb["blocks"]) == 5 and vb["min"] <= vb["median"] <= vb["max"]
+    assert 0.5 * d["value"] < vb["median"] < 2.0 * d["value"]
+    assert "smi_under_load" in d and d["smi_under_load"]["steps_run_meanwhile"] > 0
     assert d["dtype"].startswith("f32")
     assert 0.15 < r["mfma"]["frac"] < 1.0 and 0.15 < r["frac"] < 1.0 and "wino_gemm" in r["kernel"]
     assert r["traffic"] is None or r["hbm"] is None or \
@@ -68,6 +74,7 @@ def test_costvol_density_map_and_e2e_objects():
     d = _run("--no-train", "--no-alt", "--no-valu-floor", "--cpu-budget", "2")
     cv = d["roofline_costvol"]
     assert sorted(cv["frac_at_density"]) == ["0.1", "0.3", "0.5", "1.0"]
+    assert d["roofline"]["costvol_pass"]["frac_at_density"] == cv["frac_at_density"]     # inside the object the driver keeps
     assert all(0 < v < 1.2 for v in cv["frac_at_density"].values())
     assert cv["frac_at_density"]["0.1"] > cv["frac_at_density"]["0.5"] > cv["frac_at_density"]["1.0"]
     for k, v in cv["frac_at_density"].items():

@@ -10,7 +10,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # --no-alt / --no-valu-floor: no child processes under the profiler (they would inherit it and write their own stats)
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-e2e --no-train --no-density-sweep --no-alt --no-valu-floor --no-live-traffic"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-e2e --no-train --no-density-sweep --no-alt --no-valu-floor --no-live-traffic --no-blocks"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $BENCH --steps 10 --warmup 2 --no-overlap > $O/bench_profiled.json 2> $O/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
