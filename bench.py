@@ -242,6 +242,30 @@ def valu_floor(n_wave_tiles, n_mfma_per_tile=30, mfma_issue_cycles=8):
             "ubench_ms": ms}
 
 
+def bwd_valu_floor(n_tiles):
+    """The instruction-issue floor of the dense-row SpaMat backward (spamat_bwd_rowb), measured live like valu_floor():
+    tools/ubench/bwd_tile_rate.bin times one 16 x 16 band tile's own arithmetic -- per candidate fma, exp2, the weight
+    e (d - out), its split into three bf16 terms; six v_mfma_f32_16x16x32_bf16 per tile -- at 4 waves per SIMD on every
+    CU, minus the microbenchmark's loop overhead.  floor = tiles per SIMD x that; what the kernel spends beyond it is
+    addressing, LDS traffic, the per-left-tile staging and the barriers."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench", "bwd_tile_rate.bin")
+    if not os.path.exists(exe):
+        return None
+    try:
+        txt = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    except Exception:                                   # noqa: BLE001
+        return None
+    ms = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"^(.+?)\s+([0-9.]+) ms", txt, re.M)}
+    need = ("tile: vector work + six MFMAs", "inputs only (loop overhead)")
+    if any(k not in ms for k in need):
+        return None
+    ub_tiles_per_simd = 256 * 4 * 4 * 2048 / 1024.0     # the microbenchmark's grid: blocks x waves x iterations / SIMDs
+    tile_us = 1e3 * (ms[need[0]] - ms[need[1]]) / ub_tiles_per_simd
+    return {"tile_us_per_simd": tile_us, "tiles": n_tiles, "floor_ms": n_tiles / 1024.0 * tile_us * 1e-3, "ubench_ms": ms}
+
+
 def cpu_baseline(seed=17, budget_s=12.0, max_pairs=16):
     """The CPU checker (oracle/: C+OpenMP restatement of the CUDA kernels, torch-CPU stage 0)
     timed on this box's host cores, pair after pair of the same workload (the first one is a
@@ -703,6 +727,18 @@ def train_leg(dev, B=4, iters=30):
             graphed.append((Lg, Rg, rm, tm, D, go))
         row["fwd_bwd_eager_ms"] = step_ms
         row["fwd_bwd_kernels_ms"] = kernel_ms
+        if dens == 1.0:
+            # the dense stage-3 backward against ITS bound: instruction issue of its band tiles (live microbenchmark)
+            C, H, W, D = STAGES[3]
+            xt, nt = (W + 15) // 16, (D - 1 + 15) // 16 + 1
+            tiles = B * H * sum(min(x, nt - 1) + 1 for x in range(xt))
+            vf = bwd_valu_floor(tiles)
+            tb3 = row["stages"][-1]["bwd_kernel_ms"]
+            if vf:
+                row["roofline_valu"] = {"bound": "valu", "achieved": vf["floor_ms"], "peak": tb3,
+                                        "unit": "ms (floor / measured)", "frac": vf["floor_ms"] / tb3, "ms": tb3,
+                                        "kernel": "spamat backward, stage 3, dense rows (spamat_bwd_rowb + marker launches)",
+                                        "detail": vf}
         # the whole step (SpaMatFunction forward + backward, stages 1-3) as ONE HIP-graph replay: the same
         # autograd.Function, captured once (decnet_amd.graphs.GraphedStep) -- no Python / allocator work per step
         try:
@@ -720,9 +756,12 @@ def train_leg(dev, B=4, iters=30):
         step_ms = row["fwd_bwd_ms"]
         row["pairs_per_s"] = B / step_ms * 1e3
         res.append(row)
-    return {"workload": "BASELINE config 5 per-GPU share: SpaMat forward+backward, stages 1-3, "
-                        "%d pairs 972x540 max_disp 216" % B,
-            "by_density": res}
+    out = {"workload": "BASELINE config 5 per-GPU share: SpaMat forward+backward, stages 1-3, "
+                       "%d pairs 972x540 max_disp 216" % B,
+           "by_density": res}
+    if "roofline_valu" in res[0]:
+        out["roofline_valu"] = res[0].pop("roofline_valu")
+    return out
 
 
 def launch_ranks(n, argv):
@@ -884,14 +923,10 @@ def smi_under_load(step, drain, min_s=1.5):
     out = {"steps_run_meanwhile": n, "busy_s": time.perf_counter() - t0}
     try:
         card = next(iter(json.loads(box["raw"]).values()))
-        for k, v in card.items():
-            kl = k.lower()
-            if "sclk" in kl:
-                out["sclk"] = v
-            elif "mclk" in kl:
-                out["mclk"] = v
-            elif "power" in kl:
-                out.setdefault("power", {})[k] = v
+        # rocm-smi's own keys, e.g. "sclk clock speed:" -> "(2100Mhz)", "sclk clock level:" -> "1",
+        # "Current Socket Graphics Package Power (W)" -> "1297.0": kept verbatim
+        out["rocm_smi"] = {k: v for k, v in card.items()
+                           if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "socclk", "power"))}
     except Exception as e:                               # noqa: BLE001
         out["error"] = box.get("err") or "%s: %s" % (type(e).__name__, str(e)[:120])
         out["raw"] = (box.get("raw") or "")[:300]

@@ -74,17 +74,22 @@ def build(force=False, verbose=False):
 
 
 def build_ubench(force=False):
-    """tools/ubench/softmax_rate.bin: the VALU-floor microbenchmark bench.py runs beside the dense cost-volume
-    kernel (a stand-alone HIP program; a child process of bench.py, never linked into the library)."""
+    """tools/ubench/softmax_rate.bin and bwd_tile_rate.bin: the issue-floor microbenchmarks bench.py runs beside the
+    dense cost-volume kernel and the dense-row backward (stand-alone HIP programs; child processes of bench.py, never
+    linked into the library).  Returns the forward one's path."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "tools", "ubench", "softmax_rate.hip")
-    out = os.path.join(root, "tools", "ubench", "softmax_rate.bin")
-    if not os.path.exists(src):
-        return None
-    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-O3", "-w", "-fno-honor-nans", src, "-o", out])
-    return out
+    outs = []
+    for name, flags in (("softmax_rate", ["-fno-honor-nans"]), ("bwd_tile_rate", [])):
+        src = os.path.join(root, "tools", "ubench", name + ".hip")
+        out = os.path.join(root, "tools", "ubench", name + ".bin")
+        if not os.path.exists(src):
+            outs.append(None)
+            continue
+        if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-O3", "-w"] + flags + [src, "-o", out])
+        outs.append(out)
+    return outs[0]
 
 
 # ---- the compiled drop-in modules (SURVEY.md 8b "Build boundary") --------------------------------------------
