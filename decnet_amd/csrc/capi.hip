@@ -26,6 +26,15 @@ int decnet_mfma_backward(int var, const float *ref, const float *tar, const floa
                          float *grad_ref, float *grad_tar, float *grad_disp, int B, int C, int H,
                          int W, int max_disp, hipStream_t stream);
 
+// spamat_wide.hip: disparity ranges wider than 18 tiles (max_disp > 272) as several band-kernel calls + per-pixel merges
+int decnet_wide_forward(int mode, const float *ref, const float *tar, const float *rmask, const float *tmask,
+                        const float *disparity, float *out, float *var_out, float *sum_sim, float *max_cost, int B, int C,
+                        int H, int W, int D, int allow_compact, int mbits, hipStream_t stream);
+int decnet_wide_backward(int var, const float *ref, const float *tar, const float *rmask, const float *tmask,
+                         const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
+                         const float *grad_out, float *grad_ref, float *grad_tar, float *grad_disp, int B, int C, int H,
+                         int W, int D, hipStream_t stream);
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -106,6 +115,9 @@ static int backward_dispatch(int var, const float *ref, const float *tar, const 
         int rc = decnet_mfma_backward(var, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
                                       grad_out, grad_ref, grad_tar, grad_disp, B, C, H, W, max_disp,
                                       stream);
+        if (rc == DECNET_ERR_UNSUPPORTED && max_disp > 272)       // wider than 18 tiles: the same kernels band by band
+            rc = decnet_wide_backward(var, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out, grad_ref,
+                                      grad_tar, grad_disp, B, C, H, W, max_disp, stream);
         if (rc != DECNET_ERR_UNSUPPORTED || pinned >= 2) return rc;
     }
     return decnet_rowtile_backward(var, ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
@@ -126,6 +138,9 @@ static int forward_dispatch(int mode, const float *ref, const float *tar, const 
     if (pinned != 1) {
         int rc = decnet_mfma_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
                                      max_cost, B, C, H, W, max_disp, pinned != 3, 0, stream);
+        if (rc == DECNET_ERR_UNSUPPORTED && max_disp > 272)       // wider than 18 tiles: the same kernels band by band
+            rc = decnet_wide_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, B, C, H, W,
+                                     max_disp, pinned != 3, 0, stream);
         if (rc != DECNET_ERR_UNSUPPORTED || pinned >= 2) return rc;
     }
     return decnet_rowtile_forward(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,
@@ -178,15 +193,21 @@ int decnet_spamatvar_forward_bits(const float *ref, const float *tar, const unsi
     const void *p[] = {ref, tar, ref_bits, tar_bits, output, variance, sum_similarities, max_cost};
     int rc = decnet_check_spamat_args(p, 8, B, C, H, W, max_disp);
     if (rc) return rc;
-    // the matrix-core kernels only (the row-tile fallback reads float planes): band of <= 18 tiles, i.e. max_disp <= 272;
+    // the matrix-core kernels only (the row-tile fallback reads float planes); above max_disp 272 (18 tiles) band by
+    // band on masks unpacked into scratch planes (spamat_wide.hip; UNSUPPORTED while the stream is being captured).
     // DECNET_SPAMAT_KERNEL=rowtile pins a kernel this entry does not have -> UNSUPPORTED, the caller falls back to the
     // float-mask entry (decnet_amd.model does)
     if (spamat_pinned() == 1) return DECNET_ERR_UNSUPPORTED;
     if (int rc2 = check_finite(ref, tar, B, C, H, W, (hipStream_t)stream)) return rc2;
-    return decnet_mfma_forward(2, ref, tar, reinterpret_cast<const float *>(ref_bits),
-                               reinterpret_cast<const float *>(tar_bits), nullptr, output, variance,
-                               sum_similarities, max_cost, B, C, H, W, max_disp, spamat_pinned() != 3, 1,
-                               (hipStream_t)stream);
+    rc = decnet_mfma_forward(2, ref, tar, reinterpret_cast<const float *>(ref_bits),
+                             reinterpret_cast<const float *>(tar_bits), nullptr, output, variance,
+                             sum_similarities, max_cost, B, C, H, W, max_disp, spamat_pinned() != 3, 1,
+                             (hipStream_t)stream);
+    if (rc == DECNET_ERR_UNSUPPORTED && max_disp > 272)
+        rc = decnet_wide_forward(2, ref, tar, reinterpret_cast<const float *>(ref_bits),
+                                 reinterpret_cast<const float *>(tar_bits), nullptr, output, variance, sum_similarities,
+                                 max_cost, B, C, H, W, max_disp, spamat_pinned() != 3, 1, (hipStream_t)stream);
+    return rc;
 }
 
 int decnet_spamat_backward(const float *ref, const float *tar, const float *ref_mask,

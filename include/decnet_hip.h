@@ -98,7 +98,8 @@ int decnet_spamatvar_forward(const float *ref, const float *tar, const float *re
 /* decnet_spamatvar_forward with bit-packed masks: ref_bits / tar_bits [B,H,ceil(W/64)] 64-bit words, bit i of word w
  * of a row = pixel 64 w + i, zero past W (what decnet_detail_mask writes beside the float plane of the reference's
  * contract).  Same results as the float-mask call; 8 of the pass's 88 bytes per pixel (C = 8) are not read.
- * DECNET_ERR_UNSUPPORTED above max_disp 272 (no bit-mask variant of the row-tile fallback). */
+ * Above max_disp 272 the range is done in bands of <= 272 with the masks unpacked into scratch planes (stream-ordered
+ * allocation); DECNET_ERR_UNSUPPORTED there only while `stream` is being captured into a graph. */
 int decnet_spamatvar_forward_bits(const float *ref, const float *tar, const unsigned long long *ref_bits,
                                   const unsigned long long *tar_bits, float *output, float *variance,
                                   float *sum_similarities, float *max_cost, int B, int C, int H, int W,

@@ -1,0 +1,185 @@
+"""max_disp above the band kernels' 272 (18 tiles): the reference's own demo data reaches 405 / 621 at stage 3
+(demo.py:149-155: max_disp = ceil(ndisp / 27) * 27 with ndisp 400 / 610 in InputData/real/*/calib.txt).  csrc/spamat_wide.hip
+runs the matrix-core kernels band by band and merges per pixel; these tests pin it to the CPU oracle, to the reference's own
+kernels run live on the same GPU, and check that no call lands on the VALU row-tile fallback.  -m gpu.
+
+Tolerances: those of tests/test_spamat_gpu.py with the absolute disparity / variance terms scaled by D / 216 (one fp32 ulp at
+600 px is 6e-5; the reference's own sums carry the same growth)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import decnet_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+def make_case(seed, B, C, H, W, p, relu=True, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    L = torch.randn(B, C, H, W, generator=g) * scale
+    R = torch.randn(B, C, H, W, generator=g) * scale
+    if relu:
+        L, R = torch.relu(L), torch.relu(R)
+    rm = (torch.rand(B, H, W, generator=g) < p).float()
+    tm = (torch.rand(B, H, W, generator=g) < p).float()
+    return L, R, rm, tm
+
+
+def pack_bits(mk):
+    B, H, W = mk.shape
+    wpr = (W + 63) // 64
+    z = torch.zeros(B, H, wpr * 64, dtype=torch.int64, device=mk.device)
+    z[:, :, :W] = (mk != 0).long()
+    sh = torch.arange(64, device=mk.device, dtype=torch.int64)
+    return (z.view(B, H, wpr, 64) << sh).sum(-1).contiguous()
+
+
+def check_fwd(o, s, m, out, ssum, mx, D):
+    k = D / 216.0
+    out, ssum, mx = (t.cpu().numpy() for t in (out, ssum, mx))
+    np.testing.assert_allclose(mx, m, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ssum, s, rtol=4e-5, atol=1e-9)
+    np.testing.assert_allclose(out, o, rtol=1e-5, atol=2e-4 * k)
+    assert np.abs(out - o).mean() < 5e-5 * k
+
+
+WIDE = [  # B, C, H, W, D, density
+    (1, 8, 3, 700, 405, 1.0),       # real/00003: two bands
+    (2, 8, 3, 700, 405, 0.5),
+    (1, 8, 2, 900, 621, 1.0),       # three bands
+    (1, 8, 3, 900, 621, 0.2),       # sparse rows inside the bands
+    (1, 8, 2, 300, 405, 1.0),       # W < max_disp: the upper bands hold few / no candidates
+    (1, 8, 2, 280, 621, 0.6),       # the third band is empty for every pixel
+    (1, 24, 2, 400, 300, 0.8),      # more channels (no shipped stage has this width; the entry is generic)
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,D,p", WIDE)
+def test_wide_forward_vs_oracle(dev, B, C, H, W, D, p):
+    import decnet_amd
+    from decnet_amd.ext import SpaMat as SM
+    L, R, rm, tm = make_case(21, B, C, H, W, p)
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    dL, dR, drm, dtm = (t.to(dev) for t in (L, R, rm, tm))
+    o2, s2, m2 = (torch.full((B, H, W), 7.0, device=dev) for _ in range(3))        # NOT zero filled
+    assert SM.sparse_matching_cuda_forward(dL, dR, drm, dtm, o2, s2, m2, D) == 1
+    check_fwd(o, s, m, o2, s2, m2, D)
+    off = rm.numpy() == 0
+    assert (o2.cpu().numpy()[off] == 0).all() and (s2.cpu().numpy()[off] == 0).all()
+    # SpaVar around a given disparity, and the fused call (variance around its own output)
+    mu = torch.from_numpy(o) + torch.randn(B, H, W, generator=torch.Generator().manual_seed(3))
+    v, sv, mv = oracle.spavar_forward(L, R, rm, tm, mu, D)
+    var = decnet_amd.SpaVar()(dL, dR, drm, dtm, mu.to(dev), D)
+    k = (D / 216.0) ** 2
+    np.testing.assert_allclose(var.cpu().numpy(), v, rtol=2e-4, atol=2e-3 * k)
+    fo, fv, fs, fm = decnet_amd.spamatvar_forward(dL, dR, drm, dtm, D)
+    check_fwd(o, s, m, fo, fs, fm, D)
+    v_o, _, _ = oracle.spavar_forward(L, R, rm, tm, o, D)
+    np.testing.assert_allclose(fv.cpu().numpy(), v_o, rtol=2e-4, atol=2e-3 * k)
+    # bit-packed masks: the same results as the float-mask call, bit for bit
+    bo, bv, bs, bm = decnet_amd.spamatvar_forward_bits(dL, dR, pack_bits(drm), pack_bits(dtm), D)
+    for a, b_ in ((fo, bo), (fv, bv), (fs, bs), (fm, bm)):
+        assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,C,H,W,D,p", [WIDE[1], WIDE[3], WIDE[4]])
+def test_wide_backward_vs_oracle(dev, B, C, H, W, D, p):
+    import decnet_amd
+    L, R, rm, tm = make_case(23, B, C, H, W, p, relu=False, scale=0.5)
+    g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(5))
+    o, s, m = oracle.spamat_forward(L, R, rm, tm, D)
+    gl, gr = oracle.spamat_backward(L, R, rm, tm, o, s, m, g, D)
+    dL, dR = L.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+    out = decnet_amd.SpaMatFunction.apply(dL, dR, rm.to(dev), tm.to(dev), D)
+    out.backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 5e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
+    # SpaVar: three gradients
+    mu = torch.from_numpy(o) + 0.25
+    v, s2, m2 = oracle.spavar_forward(L, R, rm, tm, mu, D)
+    gl, gr, gd = oracle.spavar_backward(L, R, rm, tm, mu, v, s2, m2, g, D)
+    dL, dR, dmu = L.to(dev).requires_grad_(), R.to(dev).requires_grad_(), mu.to(dev).requires_grad_()
+    out = decnet_amd.SpaVarFunction.apply(dL, dR, rm.to(dev), tm.to(dev), dmu, D)
+    out.backward(g.to(dev))
+    sc = max(1.0, float(np.abs(gl).max()), float(np.abs(gr).max()))
+    assert np.abs(dL.grad.cpu().numpy() - gl).max() < 5e-5 * sc
+    assert np.abs(dR.grad.cpu().numpy() - gr).max() < 5e-5 * sc
+    # grad_disparity = -2 g sum e (d - mu) / S: a difference of two sums of size ~ D^2 / 12 per unit g
+    scd = max(1.0, float(np.abs(gd).max()))
+    assert np.abs(dmu.grad.cpu().numpy() - gd).max() < 2e-4 * scd * (D / 216.0)
+
+
+def test_wide_live_against_the_reference_kernels(dev):
+    """max_disp 405 (InputData/real/00003 at stage 3), a full-width plane, against the reference's own kernels on this GPU."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/*.so not built (oracle/ref_build.sh needs /root/reference)")
+    import decnet_amd
+    from decnet_amd.ext import SpaMat as SM
+    B, C, H, W, D = 1, 8, 96, 1350, 405
+    for p in (1.0, 0.3):
+        g = torch.Generator(device="cpu").manual_seed(405 + int(p * 10))
+        L = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev)
+        R = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev)
+        rm = (torch.rand(B, H, W, generator=g) < p).float().to(dev)
+        tm = (torch.rand(B, H, W, generator=g) < p).float().to(dev)
+        go = torch.randn(B, H, W, generator=g).to(dev)
+        ro, rs, rmx = ref.spamat_forward(L, R, rm, tm, D)
+        rv, _, _ = ref.spavar_forward(L, R, rm, tm, ro, D)
+        o, v, s, m = decnet_amd.spamatvar_forward(L, R, rm, tm, D)
+        check_fwd(ro.cpu().numpy(), rs.cpu().numpy(), rmx.cpu().numpy(), o, s, m, D)
+        np.testing.assert_allclose(v.cpu().numpy(), rv.cpu().numpy(), rtol=2e-4, atol=2e-3 * (D / 216.0) ** 2)
+        rgl, rgr = ref.spamat_backward(L, R, rm, tm, ro, rs, rmx, go, D)
+        gl, gr = torch.empty_like(L), torch.empty_like(R)
+        assert SM.sparse_matching_cuda_backward(L, R, rm, tm, ro, rs, rmx, go, gl, gr, D) == 1
+        torch.cuda.synchronize()
+        sc = max(1.0, float(rgl.abs().max()), float(rgr.abs().max()))
+        assert float((gl - rgl).abs().max()) < 5e-5 * sc
+        assert float((gr - rgr).abs().max()) < 5e-5 * sc
+
+
+def test_wide_is_the_matrix_core_path_not_the_row_tile_fallback():
+    """DECNET_SPAMAT_KERNEL=mfma forbids the row-tile kernels: max_disp 405 / 621 must go through (round 5: UNSUPPORTED),
+    float and bit masks, forward and backward; and the time per candidate stays within a small factor of max_disp 216."""
+    code = r'''
+import sys, time, torch
+sys.path.insert(0, %r)
+import decnet_amd
+from decnet_amd.ext import SpaMat as SM
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(1)
+def run(D, W):
+    B, C, H = 2, 8, 128
+    L = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev); R = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev)
+    rm = torch.ones(B, H, W, device=dev); tm = torch.ones(B, H, W, device=dev)
+    o = decnet_amd.spamatvar_forward(L, R, rm, tm, D)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): o = decnet_amd.spamatvar_forward(L, R, rm, tm, D)
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+    gl, gr = torch.empty_like(L), torch.empty_like(R)
+    assert SM.sparse_matching_cuda_backward(L, R, rm, tm, o[0], o[2], o[3], torch.ones(B, H, W, device=dev), gl, gr, D) == 1
+    cand = B * H * sum(min(D, x + 1) for x in range(W))
+    return t / cand
+base = run(216, 1400)
+for D in (405, 621):
+    r = run(D, 1400) / base
+    print("D", D, "time per candidate vs D=216:", round(r, 2))
+    assert r < 3.0, r
+print("OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DECNET_SPAMAT_KERNEL="mfma"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
