@@ -162,7 +162,7 @@ class HotPath:
                 if events is not None and s == 3:
                     events["s3_end"].record()
 
-        gather_own = self.coll and os.environ.get("DECNET_GATHER_STREAM", "1") != "0"
+        gather_own = self.coll
         ev3 = None
         if overlap:
             with torch.cuda.stream(self.side):

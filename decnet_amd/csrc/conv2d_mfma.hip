@@ -27,9 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef DECNET_C2M_ABLATE
-#define DECNET_C2M_ABLATE 0      // timing experiments only: 1 stage chunk 0 only, 2 never advance the weight pointer, 4 no A re-load, 8 no barriers
-#endif
 
 namespace {
 
@@ -262,7 +259,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
     for (int ck = 0; ck < nchunk; ++ck) {
         const bool more = ck + 1 < nchunk;
         const bool skip1 = !more && tail8;
-        if (more && !(DECNET_C2M_ABLATE & 17)) issue(ck + 1);   // in flight during this chunk's MFMAs
+        if (more) issue(ck + 1);   // in flight during this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
         if (wave_active) {
             // every operand tile is re-loaded for the NEXT (tap, j) step right behind its last MFMA of this one: the B
@@ -280,7 +277,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
                 for (int j = 0; j < 3; ++j) {
                     // last chunk with <= 8 real channels: its j = 1 step (channels 8-15) is all padding
                     if (j == 1 && skip1) continue;
-                    if (!(DECNET_C2M_ABLATE & 2)) wb += (j == 0 && skip1) ? 2 * wstep : wstep;   // -> the next step's tiles
+                    wb += (j == 0 && skip1) ? 2 * wstep : wstep;   // -> the next step's tiles
                     const int nxt = j == 0 ? offA[skip1 ? 2 : 1] + tapoff : j == 1 ? offA[2] + tapoff : offA[0] + tapoff_n;
 #pragma unroll
                     for (int nt = 0; nt < TN; ++nt) {
@@ -288,7 +285,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
                         for (int mt = 0; mt < TM; ++mt) {
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, a[mt]), __builtin_bit_cast(bf16x8, bq[nt]), acc[mt][nt], 0, 0, 0);
-                            if (nt == TN - 1 && !(DECNET_C2M_ABLATE & 4)) a[mt] = smem[nxt + mt * PW];
+                            if (nt == TN - 1) a[mt] = smem[nxt + mt * PW];
                         }
                         bq[nt] = wb[nt * 64];
                         __builtin_amdgcn_sched_barrier(0);
@@ -296,10 +293,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma(
                 }
             }
         }
-        if (!(DECNET_C2M_ABLATE & 8)) __syncthreads();             // the tile has been read by every wave
+        __syncthreads();             // the tile has been read by every wave
         if (more) {
-            if (!(DECNET_C2M_ABLATE & 33)) commit();
-            if (!(DECNET_C2M_ABLATE & 8)) __syncthreads();
+            commit();
+            __syncthreads();
         }
     }
 

@@ -46,9 +46,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef DECNET_C2M_ABLATE
-#define DECNET_C2M_ABLATE 0      // timing experiments only: 1 stage chunk 0 only, 2 never advance the weight pointer, 4 no A re-load, 8 no barriers
-#endif
 
 namespace {
 

@@ -131,9 +131,6 @@ __global__ __launch_bounds__(256) void conv2d_small(Segs in, const float *__rest
         }
 }
 
-#ifndef DECNET_F32M_CH
-#define DECNET_F32M_CH 1            // input channels whose taps are in flight together in conv2d_f32m
-#endif
 // ---- the same layers on the fp32 matrix pipe (round 4) ------------------------------------------------------------
 // conv2d_small above runs its multiply-adds as v_pk_fma_f32 with an SGPR weight pair: 60 - 70 TFLOP/s whatever the
 // occupancy (8 -> 8 is HBM-shaped at that rate, but 12 / 16 / 17 -> 8 -- the concatenated inputs of Deconv2dBlock,
@@ -187,7 +184,7 @@ __global__ __launch_bounds__(256) void conv2d_f32m(Segs in, const float *__restr
         for (int c = 0; c < COQ; ++c) acc[r][c] = f32x4_m{0.f, 0.f, 0.f, 0.f};
     const float *wlane = wl + (lane & 3) * COQ;
     // CHB channels per step: all their taps are requested before the first MFMA (no loop-carried tap registers)
-    constexpr int CHB = DECNET_F32M_CH;
+    constexpr int CHB = 1;            // input channels whose taps are in flight together (2: measured slower)
     int sg = 0, cs = 0;
     auto plane_ptr = [&]() { return in.p[sg] + ((size_t)b * in.c[sg] + cs) * plane; };
     auto advance = [&]() { if (++cs == in.c[sg]) { cs = 0; ++sg; } };

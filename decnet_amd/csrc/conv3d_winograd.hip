@@ -33,9 +33,6 @@
 
 #include "common.h"
 
-#ifndef DECNET_WINO_ABLATE
-#define DECNET_WINO_ABLATE 0     // timing-only builds (tools/ablate.sh): 1 no stores | 2 loads always hit |
-#endif                           // 3 no MFMA | 5 = 1 + 2 | 6 no loads
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -44,15 +41,6 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-#ifndef W3_ABLATE
-#define W3_ABLATE 0              // wino_gemm_bf16x3, timing only: 1 no V split | 2 U^T always L1 hits | 3 no U^T loads | 4 one MFMA of six
-#endif
-#ifndef DECNET_WINO_OUT_STREAM
-#define DECNET_WINO_OUT_STREAM 1
-#endif
-#ifndef DECNET_WINO_KSPLIT
-#define DECNET_WINO_KSPLIT 0
-#endif
 constexpr int W_BN = 224;      // co rows of U^T per transform point: 14 MFMA tiles of 16
 __host__ __device__ constexpr int pad16(int c) { return (c + 15) & ~15; }
 
@@ -195,11 +183,7 @@ __device__ __forceinline__ void wino_input_body(const float *__restrict__ x, flo
 #pragma unroll
             for (int k = 0; k < TW; ++k) {
                 const bool ok = okzy && (unsigned)(x0 - 1 + k) < (unsigned)g.W;
-#if DECNET_WINO_ABLATE == 7
-                r[k] = ok ? (float)(k + i) : 0.f;
-#else
                 r[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, ok ? row + k * C * 4 : OOB, 0, 0));
-#endif
             }
             bt_1d<TW>(r);
 #pragma unroll
@@ -235,11 +219,7 @@ __device__ __forceinline__ void wino_input_body(const float *__restrict__ x, flo
 #pragma unroll
         for (int jj = 0; jj < TH; ++jj)
 #pragma unroll
-#if DECNET_WINO_ABLATE == 8
-            for (int k = 0; k < KW; ++k) { if (d[i][jj][k] == 12345.678f) o[(size_t)((i * TH + jj) * TW + K0 + k) * xs] = d[i][jj][k]; }
-#else
             for (int k = 0; k < KW; ++k) o[(size_t)((i * TH + jj) * TW + K0 + k) * xs] = d[i][jj][k];
-#endif
 }
 
 template <int TD, int TH, int TW, int KS>
@@ -279,11 +259,7 @@ __device__ __forceinline__ void wino_output_body(
         for (int jj = 0; jj < TH; ++jj) {
             float m[TW], o[OW];
 #pragma unroll
-#if DECNET_WINO_ABLATE == 7
-            for (int k = 0; k < TW; ++k) m[k] = (float)(k + i + jj + tl);
-#else
             for (int k = 0; k < TW; ++k) m[k] = mp[(size_t)((i * TH + jj) * TW + k) * xs];
-#endif
             at_1d<TW>(m, o);
 #pragma unroll
             for (int k = 0; k < OWH; ++k) a[i][jj][k] = o[X0 + k];
@@ -339,12 +315,8 @@ __device__ __forceinline__ void wino_output_body(
 #pragma unroll
                 for (int k = 0; k < OWH; ++k) {
                     const int z = z0 + i, yy = y0 + j0 + jj, xx = x0 + X0 + k;
-#if DECNET_WINO_ABLATE == 8
-                    const int off = OOB;
-#else
                     const int off = z < g.D && yy < g.H && xx < g.W
                                         ? ((((b * g.D + z) * g.H + yy) * g.W + xx) * Co + co) * 4 : OOB;
-#endif
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(out[i][jj][k] + res[i][jj][k]), yr, off, 0, 0);
                 }
         if (JG < OH) __builtin_amdgcn_sched_barrier(0);
@@ -443,9 +415,6 @@ __device__ __forceinline__ void wino_output_stream6(
             for (int k = 0; k < OW; ++k) {
                 float v = fmaf(acc[i][jj][k], sc, sh);
                 if (relu) v = fmaxf(v, 0.f);
-#if DECNET_WINO_ABLATE == 8
-                off[jj][k] = OOB;
-#endif
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v + res[jj][k]), yr, off[jj][k], 0, 0);
             }
     }
@@ -463,7 +432,7 @@ __global__ __launch_bounds__(256) void wino_output_transform(
     const size_t q = idx >> 4;
     const int cg = (int)(q / nt), tl = (int)(q - (size_t)cg * nt);
     if (cg >= CG || cg * 16 + (int)(idx & 15) >= Co) return;
-    if (TD == 6 && KS == 1 && DECNET_WINO_OUT_STREAM) {
+    if (TD == 6 && KS == 1) {
         wino_output_stream6<TH, TW>(M, scale, shift, residual, y, g, Co, relu, t_lo, nt, y_bytes, cg, tl, (int)(idx & 15));
         return;
     }
@@ -642,7 +611,7 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
     const float *__restrict__ shift, const float *__restrict__ res_in, float *__restrict__ res_out, Tiling g,
     int C, int nt, int relu) {
     extern __shared__ float ys[];                       // [D][H][4][Wp]
-    constexpr int T = 6, O = 4;
+    constexpr int O = 4;
     const int Wp = g.W | 1, vol = g.D * g.H * 4 * Wp;
     const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;     // quads with data, quads per transform point
     const int b = blockIdx.x / nq, cq = blockIdx.x - b * nq;
@@ -842,17 +811,10 @@ __device__ __forceinline__ void wino_gemm_wave(const float *__restrict__ Vb, con
     // (p, c) = point (relative) and chunk; beyond the last point the offsets go out of range: zeros, no traffic
     auto load = [&](f32x4(&v)[TM], f32x4(&u)[TN], int p, int c, auto nk) {
         constexpr int NK = decltype(nk)::value;                       // k per lane in this chunk
-#if DECNET_WINO_ABLATE == 6
-        if (p + c > 0) return;
-#endif
         bool ok = p < xg;
         if (NFULL == 0) ok = ok && c * 16 + kq * 4 < Ci;              // K tail: whole 16-byte groups (Ci % 4 == 0)
-#if DECNET_WINO_ABLATE == 2 || DECNET_WINO_ABLATE == 5
-        const int vb = xi0 * v_point + kq * (4 * NK), ub = xi0 * u_point + kq * (4 * NK);
-#else
         const int vb = (xi0 + p) * v_point + c * v_chunk + kq * (4 * NK);
         const int ub = (xi0 + p) * u_point + c * u_chunk + kq * (4 * NK);
-#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) v[i] = buf_load<NK>(vr, ok && v_row[i] != OOB ? v_row[i] + vb : OOB);
 #pragma unroll
@@ -871,18 +833,10 @@ __device__ __forceinline__ void wino_gemm_wave(const float *__restrict__ Vb, con
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-#if DECNET_WINO_ABLATE == 3
-                    acc[j][i][0] += u[j][t] * v[i][t];
-#else
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][t], v[i][t], acc[j][i], 0, 0, 0);
-#endif
     };
     auto finish = [&](int p) {                          // transform point finished: store and clear
-#if DECNET_WINO_ABLATE == 1 || DECNET_WINO_ABLATE == 5
-        const int pb = OOB - 0x10000000;
-#else
         const int pb = (xi0 + p) * m_point + kq * 16;
-#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cg = wn * 7 + J0 + j;             // 16-co group: rows 4kq + r of MFMA tile j
@@ -1138,30 +1092,15 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
 #pragma unroll
-#if W3_ABLATE == 1                                      // timing only: no split of V
-        for (int i = 0; i < TM; ++i) {
-            vs[i][0] = __builtin_bit_cast(i32x4, vf[i][0]); vs[i][1] = __builtin_bit_cast(i32x4, vf[i][1]);
-            vs[i][2] = vs[i][0] ^ vs[i][1];
-        }
-#else
         for (int i = 0; i < TM; ++i) split3(vf[i][0], vf[i][1], vs[i][0], vs[i][1], vs[i][2]);
-#endif
         load_v(p + 1);                                  // vf is free again
 #pragma unroll
         for (int g = 0; g < (TN + 1) / 2; ++g) {        // tiles 2g, 2g+1 (the last group has one tile + a dummy)
             const int s = p * 8 + 2 * g;                // ring position: 8 slots per pair (7 tiles + 1 dummy)
             {
                 const int sn = s + 2, pn = sn / 8, jn = sn % 8;
-#if W3_ABLATE == 2                                      // timing only: the U^T tiles of pair 0 again and again (L1 hits)
-                if (jn < TN) load_u(sn % RING, jn);
-                if (jn + 1 < TN) load_u((sn + 1) % RING, jn + 1);
-#elif W3_ABLATE == 5                                    // timing only: every other U^T tile loaded (half the requests)
-                if (jn < TN) load_u(sn % RING, pn * TN + jn);
-#elif W3_ABLATE == 3                                    // timing only: no U^T loads after the first two
-#else
                 if (jn < TN) load_u(sn % RING, pn * TN + jn);
                 if (jn + 1 < TN) load_u((sn + 1) % RING, pn * TN + jn + 1);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1171,7 +1110,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(TM > 3
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int j = 2 * g + jj;
-                        if (j < TN && (W3_ABLATE != 4 || t == 0))     // 4: one product of six
+                        if (j < TN)
                             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, ub[(s + jj) % RING][UT[t]]),
                                 __builtin_bit_cast(bf16x8, vs[i][VT[t]]), acc[j][i], 0, 0, 0);
@@ -1225,8 +1164,7 @@ int gemm_dispatch(const float *V, const float *U, float *M, int nt, int Ci, int 
         return decnet_launch_status();
     }
     if (v_quad || m_quad) return DECNET_ERR_UNSUPPORTED;
-    static const int gemm_static = [] { const char *e = getenv("DECNET_WINO_GEMM"); return e && !strcmp(e, "static") ? 1 : 0; }();
-    if (!gemm_static && Ci == 216 && np >= 8) {
+    if (Ci == 216 && np >= 8) {
         hipLaunchKernelGGL((wino_gemm_persist<13, 2>), dim3(512), dim3(256), 0, s, V, U, M, nt, Ci, Co, np);
         return decnet_launch_status();
     }
@@ -1250,7 +1188,7 @@ int conv_variant(const float *x, const float *u, const float *scale, const float
                  const float *residual, float *y, float *workspace, int B, int D, int H, int W, int Ci,
                  int Co, int relu, hipStream_t s) {
     constexpr int TD = OD + 2, TH = OH + 2, TW = OW + 2, NP = TD * TH * TW;
-    constexpr int KS = (TW == 6 && DECNET_WINO_KSPLIT) ? 2 : 1;      // threads per (tile, channel) in the transforms
+    constexpr int KS = 1;      // threads per (tile, channel) in the transforms (2: measured slower, round 3)
     Tiling g{D, H, W, ceil_div(D, OD), ceil_div(H, OH), ceil_div(W, OW)};
     const double Td = (double)B * g.Td * g.Th * g.Tw;
     if (Td >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;

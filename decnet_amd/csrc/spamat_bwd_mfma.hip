@@ -687,270 +687,25 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? 4 : 2)) void spamat_bwd_sparse
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dense rows, C <= 8, SpaMat (round 4): BOTH gradients from ONE pass over the cost / weight tiles (spamat_bwd_roww below).
+// Dense rows, C <= 8, SpaMat: BOTH gradients from ONE pass over the cost / weight tiles (spamat_bwd_rowb below).
 // The two band launches above form every 16 x 16 cost tile, its exponentials and weights twice (once per side) and each
 // reads both feature rows: stage 3, B = 4: 0.75 ms, 1.63 x the algorithmic bytes.  One pass needs the weight tile
 //   w = e (d - out)    (rows = right pixels, columns = left pixels; SM_kernel.cu:191)
 // in both orientations:  gL[c][left] += sum_right w R[c][right]  and  gR[c][right] += sum_left w g/S L[c][left]
 // (SM_kernel.cu:143-195, 300-355), and gR of a right tile collects from the NT left tiles xt .. xt + NT - 1.
-// Three forms were built and measured at stage 3 (B = 4 / B = 8, backward through the autograd Function; the band
-// launches: 0.81 / 1.53 ms); the first two are in the repository's history (commit "one-pass dense-row SpaMat backward"):
-//   one wave per row, contractions on v_mfma_f32_16x16x4_f32, a window of NT accumulator tiles      0.80 / 1.33 ms
-//   the same with the contractions on v_mfma_f32_4x4x1_16B_f32 (half the contraction cycles)          0.72 / 1.33 ms
-//   four waves per row, each owning the right tiles t = w (mod 4) (below)                             0.55 / 1.00 ms
-// The first two are bound by the single wave's dependency chain (cost MFMA -> weights -> LDS round trip -> contraction,
-// 15 tiles per left tile) at 3 waves per SIMD; halving their MFMA cycles changed nothing.
-constexpr int ROW_RING = 16;                              // ring of right tiles (>= NT, a power of two)
-constexpr int ROW_RP = ROW_RING * 16 + 4;                 // feature ring pitch == 4 (mod 64)
-
-// ---- the contractions: v_mfma_f32_4x4x1_16B_f32 (no channel padding) ---------------------------------------------------
-// On the 16 x 16 x 4 instruction the contractions would land on 16 channel columns of which C = 8 exist.  The 4 x 4 x 1
-// instruction (16 independent 4 x 4 outer products per wave-instruction, K = 1; tools/ubench/mfma4x4.hip: 10 cycles per
-// instruction from two accumulator chains) has no such padding: block b = lane / 4 = (kh, g, cg) takes
-//     left gradient:  rows i = left pixels 4g + i, columns e = channels 4cg + e, K = the 8 right pixels 8kh .. 8kh + 7
-//     right gradient: rows i = right pixels 4g + i, columns e = channels 4cg + e, K = the 8 left pixels 8kh .. 8kh + 7
-// i.e. 16 x 8 outputs x two K halves per instruction, 8 instructions per contraction (64 cycles against 128), the two
-// halves added once per tile column (one cross-half shuffle of four registers).  The weight tile comes out of the
-// 16 x 16 x 4 cost MFMAs (lane (j, q), register r = right pixel 4q + r, left pixel j) and goes through LDS in both
-// orientations -- TL[left][right] by one ds_write_b128, TR[right][left] by four ds_write_b32 (per-wave scratch, in-order
-// LDS: no barrier) -- so that every lane reads its 8 A values of a contraction with two ds_read_b128; the B values are two
-// ds_read_b128 of the feature ring (left gradient) or eight registers per left tile (right gradient: g/S-scaled left
-// features, staged once per left tile).
-constexpr int ROW4_TP = 20;                               // pitch of the two weight-tile copies (floats; rows 16-byte aligned)
-
-// ---- four waves per row -----------------------------------------------------------------------------------------------
-// A 256-thread workgroup owns the row and wave w owns the RIGHT tiles t = w (mod 4): for left tile xt it forms the (at
-// most four) band tiles m = xt - t of its right tiles, so its right-gradient window is 4 accumulator tiles, not NT (a
-// right tile keeps its owner while xt advances; the window slides when m0 = (xt - w) mod 4 wraps; the tile at
-// m = NT - 1 is complete and stored), the per-wave dependency chain is 4 tiles long and 4 waves fit a SIMD without
-// spills.  Shared by the workgroup: the ring of the last 16 right tiles (features [8][RP], mask bias), the g/S-scaled
-// left features and g/S of the current left tile (committed by wave 0 from registers it fetched one tile ahead; barrier
-// 1), and the four partial left gradients of a left tile (barrier 2; summed in a fixed wave order by 32 lanes of wave
-// xt mod 4, which also stores them).  Right tiles left of the row are skipped; nothing is atomic, every input byte is
-// read once, every gradient byte written once.
-#ifndef DECNET_BWD_ROWW_NW
-#define DECNET_BWD_ROWW_NW 4           // waves per row of spamat_bwd_roww (4 or 8)
-#endif
-#ifndef DECNET_BWD_ROWW_OCC
-#define DECNET_BWD_ROWW_OCC 4          // waves per SIMD the register allocation is held to (measured at stage 3, B = 4:
-                                      // unconstrained (162 registers, 3 waves) 0.63 ms, 4: 0.55, 5 (spills): 0.75; 8 waves per row: 0.68)
-#endif
-constexpr int ROWW_NW = DECNET_BWD_ROWW_NW;
-constexpr int ROWW_LDS_FLOATS = 8 * ROW_RP + ROW_RING * 16 + ROWW_NW * 2 * 16 * ROW4_TP + 8 * 16 + 16 + ROWW_NW * 128;
-
-template <int NT>
-__global__ __launch_bounds__(64 * ROWW_NW, DECNET_BWD_ROWW_OCC) void spamat_bwd_roww(
-    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
-    const float *__restrict__ tmask, const float *__restrict__ out, const float *__restrict__ sum_sim,
-    const float *__restrict__ max_cost, const float *__restrict__ grad_out, float *__restrict__ grad_ref,
-    float *__restrict__ grad_tar, int C, int H, int W, int D, int marker) {
-    static_assert(NT <= ROW_RING, "band wider than the ring");
-    constexpr int RP = ROW_RP, TP = ROW4_TP, NW = ROWW_NW, KS = (NT + NW - 1) / NW, NTHR = 64 * NW;
-    __shared__ __attribute__((aligned(16))) float smem[ROWW_LDS_FLOATS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *RF = smem;                                    // [8][RP]: right features of the last 16 tiles (ring)
-    float *BZ = smem + 8 * RP;                           // [16 * 16]: 0 / -1e30 of the right mask (ring)
-    float *TL = BZ + ROW_RING * 16 + wave * 2 * 16 * TP; // this wave's weight tile, rows = left pixels
-    float *TR = TL + 16 * TP;                            // ... rows = right pixels
-    float *LQ = smem + 8 * RP + ROW_RING * 16 + NW * 2 * 16 * TP;   // [8][16]: g/S-scaled left features of the left tile
-    float *GS = LQ + 8 * 16;                             // [16]: g/S of the left tile's pixels
-    float *GLP = GS + 16;                                // [4 waves][32 lanes][4]: partial left gradients
-    const int row = blockIdx.x, b = row / H, y = row - b * H;
-    const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
-    const size_t frow = ((size_t)b * C * H + y) * W;
-    if (marker && __float_as_int(grad_ref[frow]) != BWD_MARK) return;    // (block-uniform) the sparse-row launches took this row
-    const float *lrow = ref + frow, *rrow = tar + frow;
-    float *glrow = grad_ref + frow, *grrow = grad_tar + frow;
-    const int j = lane & 15, q = lane >> 4;              // cost-tile coordinates
-    const int e4 = lane & 3, cg = (lane >> 2) & 1, g4 = (lane >> 3) & 3, kh = lane >> 5;   // contraction coordinates
-    const int cc4 = 4 * cg + e4;
-    const int XT = (W + 15) >> 4;
-    const bool al4 = (W & 3) == 0 && ((((uintptr_t)grad_ref) | ((uintptr_t)grad_tar)) & 15) == 0;
-    for (int i = threadIdx.x; i < 8 * RP; i += NTHR) RF[i] = 0.f;         // tiles left of the row: zero features, mask off
-    for (int i = threadIdx.x; i < ROW_RING * 16; i += NTHR) BZ[i] = NEG_BIG;
-
-    const int lc = lane >> 3, lp = 2 * (lane & 7);       // wave 0's staging of LQ / GS: (channel, pixel pair)
-    float nR[2], nL[2], nTm = 0.f, nMax, nOut, nRm, nL2[2], nG2[2], nS2[2], nM2[2];
-    auto fetch = [&](int xt) {
-        const int x = xt * 16 + j;
-        const bool ok = xt < XT && x < W;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) nL[s] = (ok && 4 * s + q < C) ? lrow[(size_t)(4 * s + q) * plane + x] : 0.f;
-        nRm = ok ? rmask[rowpix + x] : 0.f;
-        nMax = ok ? max_cost[rowpix + x] : 0.f;
-        nOut = ok ? out[rowpix + x] : 0.f;
-        if (wave == 0) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) nR[s] = (ok && 4 * s + q < C) ? rrow[(size_t)(4 * s + q) * plane + x] : 0.f;
-            nTm = ok ? tmask[rowpix + x] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int xp = xt * 16 + lp + u;
-                const bool okp = xt < XT && xp < W;
-                nL2[u] = (okp && lc < C) ? lrow[(size_t)lc * plane + xp] : 0.f;
-                nG2[u] = okp ? grad_out[rowpix + xp] : 0.f;
-                nS2[u] = okp ? sum_sim[rowpix + xp] : 1.f;
-                nM2[u] = okp ? rmask[rowpix + xp] : 0.f;
-            }
-        }
-    };
-    fetch(0);
-
-    f32x4 gr[KS];                        // gr[k]: right tile xt - (m0 + 4k); lane (kh, g, cg, e), register i: pixel 4g + i, channel 4cg + e
-#pragma unroll
-    for (int k = 0; k < KS; ++k) gr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto xhalf = [&](f32x4 v) {                          // + the other K half's partial sums (lane ^ 32)
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = v[r] + __shfl_xor(v[r], 32);
-        return o;
-    };
-    auto store_right = [&](int t, const f32x4 &gpart) {  // right tile t complete -> grad_tar (0 where the right mask is off)
-        if (t < 0) return;                               // (wave-uniform)
-        const f32x4 gsum = xhalf(gpart);
-        const int x = t * 16 + 4 * g4;
-        if (kh != 0 || cc4 >= C || x >= W) return;
-        const float4 bz = *reinterpret_cast<const float4 *>(BZ + (t & (ROW_RING - 1)) * 16 + 4 * g4);
-        float *gp = grrow + (size_t)cc4 * plane + x;
-        const float o[4] = {bz.x == 0.f ? gsum[0] : 0.f, bz.y == 0.f ? gsum[1] : 0.f, bz.z == 0.f ? gsum[2] : 0.f,
-                            bz.w == 0.f ? gsum[3] : 0.f};
-        if (al4 && x + 3 < W) {
-            *reinterpret_cast<float4 *>(gp) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (x + r < W) gp[r] = o[r];
-        }
-    };
-    __syncthreads();                                     // the zeroed ring
-
-    for (int xt = 0; xt < XT; ++xt) {
-        const int x0 = xt * 16, s0 = xt & (ROW_RING - 1);
-        const int m0 = (xt - wave) & (NW - 1);           // this wave's band tiles: m0, m0 + NW, ...
-        if (xt > 0 && m0 == 0) {                         // the window slides: a new right tile (t = xt) enters at k = 0
-#pragma unroll
-            for (int k = KS - 1; k > 0; --k) gr[k] = gr[k - 1];
-            gr[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (wave == 0) {                                 // commit tile xt (ring slot s0 held right tile xt - 16: dead)
-            RF[q * RP + s0 * 16 + j] = nR[0];
-            RF[(q + 4) * RP + s0 * 16 + j] = nR[1];
-            if (q == 0) BZ[s0 * 16 + j] = nTm != 0.f ? 0.f : NEG_BIG;
-            float gsv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) gsv[u] = nM2[u] != 0.f ? nG2[u] / nS2[u] : 0.f;   // g / S, 0 where the left mask is off
-            LQ[lc * 16 + lp] = nL2[0] * gsv[0];          // SM_kernel.cu:346: g/S L[c][left]
-            LQ[lc * 16 + lp + 1] = nL2[1] * gsv[1];
-            if (lc == 0) { GS[lp] = gsv[0]; GS[lp + 1] = gsv[1]; }
-        }
-        const float bcur[2] = {nL[0], nL[1]};
-        const float nm_own = nRm != 0.f ? -nMax * LOG2E : NEG_BIG;   // masked-off / out-of-row left pixel: weights 0
-        const float out_own = nOut;
-        fetch(xt + 1);
-        __syncthreads();                                 // (1) tile xt is in the ring, LQ / GS are this left tile's
-        const float4 lq0 = *reinterpret_cast<const float4 *>(LQ + cc4 * 16 + 8 * kh);
-        const float4 lq1 = *reinterpret_cast<const float4 *>(LQ + cc4 * 16 + 8 * kh + 4);
-        const float lqv[8] = {lq0.x, lq0.y, lq0.z, lq0.w, lq1.x, lq1.y, lq1.z, lq1.w};
-        const float dj = (float)(j - 4 * q) - out_own;   // d - out = 16 m - r + dj
-        f32x4 gl = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const int m = m0 + NW * k;
-            if (m >= NT || m > xt) continue;             // (wave-uniform) outside the band / left of the row
-            const int ob = ((xt - m) & (ROW_RING - 1)) * 16;
-            f32x4 cst = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[q * RP + ob + j], bcur[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            cst = __builtin_amdgcn_mfma_f32_16x16x4f32(RF[(q + 4) * RP + ob + j], bcur[1], cst, 0, 0, 0);
-            const float4 rb0 = *reinterpret_cast<const float4 *>(RF + cc4 * RP + ob + 8 * kh);
-            const float4 rb1 = *reinterpret_cast<const float4 *>(RF + cc4 * RP + ob + 8 * kh + 4);
-            const float4 bz = *reinterpret_cast<const float4 *>(BZ + ob + 4 * q);
-            const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
-            const float dm = (float)(16 * m) + dj;
-            f32x4 wt;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 16 * m + j - (4 * q + r);
-                float cc = cst[r] + bzv[r];
-                cc = (unsigned)d < (unsigned)D ? cc : NEG_BIG;            // 0 <= d < D (edge tiles of the band)
-                const float e = __builtin_amdgcn_exp2f(fmaf(cc, LOG2E, nm_own));
-                wt[r] = e * (dm - (float)r);                              // SM_kernel.cu:191
-            }
-            // the previous tile's contraction reads of TL / TR (other lanes of this wave) come before these stores
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<float4 *>(TL + j * TP + 4 * q) = make_float4(wt[0], wt[1], wt[2], wt[3]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) TR[(4 * q + r) * TP + j] = wt[r];
-            // lane (j, q) wrote, lane (g, e, kh) reads: a hand-off inside the wave.  The LDS executes a wave's accesses in
-            // order, so no instruction is needed -- but the COMPILER must not move the reads above the stores: a
-            // wavefront-scope release / barrier / acquire (they emit nothing) makes that ordering formal
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // left gradient: A = W[right 8kh + s][left 4g + e], B = R[4cg + e][right 8kh + s]
-            {
-                const float4 a0 = *reinterpret_cast<const float4 *>(TL + (4 * g4 + e4) * TP + 8 * kh);
-                const float4 a1 = *reinterpret_cast<const float4 *>(TL + (4 * g4 + e4) * TP + 8 * kh + 4);
-                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                const float bv[8] = {rb0.x, rb0.y, rb0.z, rb0.w, rb1.x, rb1.y, rb1.z, rb1.w};
-#pragma unroll
-                for (int s = 0; s < 8; ++s) gl = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], bv[s], gl, 0, 0, 0);
-            }
-            // right gradient: A = W[right 4g + e][left 8kh + s], B = g/S L[4cg + e][left 8kh + s]
-            {
-                const float4 a0 = *reinterpret_cast<const float4 *>(TR + (4 * g4 + e4) * TP + 8 * kh);
-                const float4 a1 = *reinterpret_cast<const float4 *>(TR + (4 * g4 + e4) * TP + 8 * kh + 4);
-                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-                for (int s = 0; s < 8; ++s) gr[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], lqv[s], gr[k], 0, 0, 0);
-            }
-            if (m == NT - 1) {                           // right tile xt - m has seen all its left tiles
-                store_right(xt - m, gr[k]);
-                gr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        // this wave's share of the left tile's gradient -> LDS; summed in wave order by wave xt mod 4
-        {
-            const f32x4 gsum = xhalf(gl);
-            if (kh == 0) *reinterpret_cast<float4 *>(GLP + wave * 128 + lane * 4) = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
-        }
-        float4 gs4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (wave == (xt & (NW - 1)) && kh == 0) gs4 = *reinterpret_cast<const float4 *>(GS + 4 * g4);
-        __syncthreads();                                 // (2) partials complete; LQ / GS / the ring slot may be overwritten
-        if (wave == (xt & (NW - 1)) && kh == 0) {
-            float4 acc = *reinterpret_cast<const float4 *>(GLP + lane * 4);
-#pragma unroll
-            for (int w2 = 1; w2 < NW; ++w2) {
-                const float4 p2 = *reinterpret_cast<const float4 *>(GLP + w2 * 128 + lane * 4);
-                acc.x += p2.x; acc.y += p2.y; acc.z += p2.z; acc.w += p2.w;
-            }
-            // lane (g, cg, e): left pixels x0 + 4g + i, channel 4cg + e: grad_ref = g * sum / S (SM_kernel.cu:193)
-            const int x = x0 + 4 * g4;
-            if (cc4 < C && x < W) {
-                float *gp = glrow + (size_t)cc4 * plane + x;
-                const float o[4] = {acc.x * gs4.x, acc.y * gs4.y, acc.z * gs4.z, acc.w * gs4.w};
-                if (al4 && x + 3 < W) {
-                    *reinterpret_cast<float4 *>(gp) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (x + r < W) gp[r] = o[r];
-                }
-            }
-        }
-    }
-    // right tiles still open after the last left tile (those at m = NT - 1 were stored in the loop)
-    {
-        const int m0 = (XT - 1 - wave) & (NW - 1);
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const int m = m0 + NW * k;
-            if (m < NT - 1) store_right(XT - 1 - m, gr[k]);
-        }
-    }
-}
-
-// ---- round 6: the same one-pass dense-row backward with every matrix product on the bf16 pipe (bf16x3) ---------------------
-// spamat_bwd_roww above spends, per 16 x 16 tile and wave, 224 matrix-pipe cycles (two fp32 cost MFMAs + sixteen 4x4x1
+// Work split (round 4, measured against one wave per row with a window of NT accumulator tiles: 0.55 vs 0.80 ms): a
+// 256-thread workgroup owns the row and wave w owns the RIGHT tiles t = w (mod 4): for left tile xt it forms the (at most
+// four) band tiles m = xt - t of its right tiles, so its right-gradient window is 4 accumulator tiles, not NT (a right
+// tile keeps its owner while xt advances; the window slides when m0 = (xt - w) mod 4 wraps; the tile at m = NT - 1 is
+// complete and stored), the per-wave dependency chain is 4 tiles long and 4 waves fit a SIMD without spills.  Shared by
+// the workgroup: the ring of the last 16 right tiles, the left tile's operands (committed before barrier 1 from values
+// fetched one tile ahead), and the four partial left gradients of a left tile (barrier 2; summed in a fixed wave order
+// by wave xt mod 4, which also stores them).  Right tiles left of the row are skipped; nothing is atomic, every input
+// byte is read once, every gradient byte written once.
+// Round 4's kernel of this shape (spamat_bwd_roww: fp32 cost MFMAs, the weight tile through LDS as fp32 in both
+// orientations, contractions on v_mfma_f32_4x4x1; 0.53 - 0.55 ms) is in the repository's history.
+// ---- round 6: every matrix product of that pass on the bf16 pipe (bf16x3) -------------------------------------------------
+// spamat_bwd_roww spent, per 16 x 16 tile and wave, 224 matrix-pipe cycles (two fp32 cost MFMAs + sixteen 4x4x1
 // contractions), ~80 vector instructions and ~60 LDS cycles (the weight tile goes through LDS as fp32 in both orientations);
 // the three pipes barely overlap: 0.53 ms at stage 3, B = 4 (profiles/r04c_pmc_sq_spamat_bwd_roww.txt).  Here
 //   * cost tile: both views as three bf16 terms, two v_mfma_f32_16x16x32_bf16 (K = 8 channels x 4 term pairs: hh hm mh mm |
@@ -965,7 +720,7 @@ __global__ __launch_bounds__(64 * ROWW_NW, DECNET_BWD_ROWW_OCC) void spamat_bwd_
 //     (four ds_read_b64_tr_b16); B = g/S-scaled left features, one image per left tile;
 //   * the N halves (terms of the features) are added once per finished gradient tile, not per band tile.
 // Products below 2^-24 relative are dropped (m l, l l on the weight side), like the forward's dense rows.  Work split, window of
-// right tiles, barriers and the fixed summation order are those of spamat_bwd_roww.
+// right tiles, barriers and the fixed summation order are described above.
 // Images: one pixel = 64 bytes = four 16-byte chunks (h | m | l | zero) of 8 channels; chunk c of pixel p sits at
 // 64 p + 16 (c ^ sw(p)), sw = 0, 2, 1, 3 for p / 4 = 0 .. 3: the cost operand reads (ds_read_b128, one chunk per lane) and
 // the transposed reads (8 bytes per lane) are both bank-conflict free.
@@ -1265,14 +1020,8 @@ template <int NT>
 int launch_row(const float *ref, const float *tar, const float *rmask, const float *tmask, const float *out,
                const float *sum_sim, const float *max_cost, const float *grad_out, float *grad_ref, float *grad_tar,
                int B, int C, int H, int W, int D, int marker, hipStream_t stream) {
-    // DECNET_SPAMAT_BWD=roww: round 4's form of the same pass (fp32 MFMAs, contractions on v_mfma_f32_4x4x1)
-    static const int roww = [] { const char *e = getenv("DECNET_SPAMAT_BWD"); return e && !strcmp(e, "roww"); }();
-    if (roww)
-        hipLaunchKernelGGL((spamat_bwd_roww<NT>), dim3((unsigned)((size_t)B * H)), dim3(64 * ROWW_NW), 0, stream, ref, tar, rmask,
-                           tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, C, H, W, D, marker);
-    else
-        hipLaunchKernelGGL((spamat_bwd_rowb<NT>), dim3((unsigned)((size_t)B * H)), dim3(64 * RB_NW), 0, stream, ref, tar, rmask,
-                           tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, C, H, W, D, marker);
+    hipLaunchKernelGGL((spamat_bwd_rowb<NT>), dim3((unsigned)((size_t)B * H)), dim3(64 * RB_NW), 0, stream, ref, tar, rmask,
+                       tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, C, H, W, D, marker);
     return decnet_launch_status();
 }
 
@@ -1284,10 +1033,9 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
     const int xt0 = side_xt<NT, VAR, 0>(4 * KQ, W), xt1 = side_xt<NT, VAR, 1>(4 * KQ, W);
     if (!xt0 || !xt1) return DECNET_ERR_UNSUPPORTED;
     // sparse rows first (C <= 24, rows of <= 2048 pixels), the rest by the marker launches
-    static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
     int marker = 0;
     if constexpr (KQ <= 6) {
-        if (!sparse_off && W <= 2048) {
+        if (W <= 2048) {
             marker = 1;
             const int ppt = W <= 1024 ? 4 : 8;
             const size_t slds = 4 * sb_words(KQ, ppt, SB_CAP, SB_THREADS);
@@ -1328,11 +1076,10 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
             }
         }
     }
-    // dense rows at C <= 8 (SpaMat): both gradients from one pass, four waves per row (DECNET_SPAMAT_BWD=band: the two
-    // band launches below, which stay the path of SpaVar and of C > 8)
-    static const int band_only = [] { const char *e = getenv("DECNET_SPAMAT_BWD"); return e && !strcmp(e, "band"); }();
+    // dense rows at C <= 8 (SpaMat): both gradients from one pass, four waves per row (the two band launches below stay
+    // the path of SpaVar, of C > 8 and of rows narrower than the band)
     if constexpr (KQ == 2 && !VAR && NT <= 15) {
-        if (!band_only && W >= 16 * NT)
+        if (W >= 16 * NT)
             return launch_row<NT>(ref, tar, rmask, tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, B, C, H, W,
                                   D, marker, stream);
     }

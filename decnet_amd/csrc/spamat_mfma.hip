@@ -38,13 +38,6 @@
 
 #include "common.h"
 
-#ifndef DECNET_ABLATE
-#define DECNET_ABLATE 0   // 1: skip MFMAs, 2: skip softmax passes, 3: both (diagnostic builds only,
-#endif                    // tools/ablate.sh, tools/dev_spamat.sh; results are wrong by construction);
-                          // 5: fp32 layouts, masks + R staging only; 6: sparse-row bodies without the matching;
-                          // dense stage-3 rows, leaving the band kernel earlier and earlier: 8 launch + marker, 9 + mask
-                          // phase, 10 + first half pass's staging, 7 + second half's; 11 = 7 without the second half's
-                          // loads, 12 = 7 without the bf16 term split (docs/rounds/r05.md)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -507,12 +500,7 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = pre[c];
             } else {
-#if DECNET_ABLATE == 11     // timing-only: the second half pass without its memory round trip
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = make_float4(1.f * it, 2.f, 3.f, 4.f);
-#else
                 dense16_loads8(v, src, plane, g, C, x, W, al);
-#endif
             }
             const int P = isL ? PL : PR;
             int *dst = (isL ? LT : RT) + (g * 4 * P + jq) * 4;
@@ -523,13 +511,7 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
 #pragma unroll
                 for (int c = 0; c < 8; ++c) xv[c] = pz == 0 ? v[c].x : pz == 1 ? v[c].y : pz == 2 ? v[c].z : v[c].w;
                 i32x4 th, tm, tl;
-#if DECNET_ABLATE == 12     // timing-only: staging without the bf16 term split
-                th = i32x4{__float_as_int(xv[0]), __float_as_int(xv[1]), __float_as_int(xv[2]), __float_as_int(xv[3])};
-                tm = i32x4{__float_as_int(xv[4]), __float_as_int(xv[5]), __float_as_int(xv[6]), __float_as_int(xv[7])};
-                tl = th;
-#else
                 split3x8(xv, th, tm, tl);
-#endif
                 *reinterpret_cast<i32x4 *>(dst + pz * 4 * P) = th;
                 *reinterpret_cast<i32x4 *>(dst + tstride + pz * 4 * P) = tm;
                 *reinterpret_cast<i32x4 *>(dst + 2 * tstride + pz * 4 * P) = tl;
@@ -537,9 +519,6 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
         }
     }
     __syncthreads();
-#if DECNET_ABLATE == 7 || DECNET_ABLATE == 10 || DECNET_ABLATE == 11 || DECNET_ABLATE == 12     // timing-only: masks + both (10: the first) staging phases of a dense row, no cost tiles, no softmax
-    return;
-#endif
 
     const int j = lane & 15, q = lane >> 4;
     const int dl = j - 4 * q;                                            // d = 16 m + dl - r
@@ -580,7 +559,6 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
         const int *a_big = RT + (tA_big * cg_n * 4 * PR + sa) * 4;
         const int *b_small = LT + (tB_small * cg_n * 4 * PL + sb) * 4;
         const int *b_big = LT + (tB_big * cg_n * 4 * PL + sb) * 4;
-#if !(DECNET_ABLATE & 1)
         // (round 5: an explicit software pipeline of this section -- operand reads 3 / 4 / 6 MFMAs ahead, the bias read of
         // a tile two MFMAs ahead of its first MFMA, pinned with sched_barrier -- measured 0.385 - 0.39 ms against 0.385 - 0.39:
         // the compiler's one-read-ahead order is not what the pass waits for; profiles/r05z2_*)
@@ -603,17 +581,6 @@ __device__ __forceinline__ void dense16_body(int *RT, const float *BX, const flo
                 }
             }
         }
-#else
-        acc[0][0] += __int_as_float(*(a_small + 3) ^ *(a_big + 5) ^ *(b_small + 1) ^ *(b_big + 2)) * 1e-30f;
-#endif
-#if DECNET_ABLATE & 2
-        {
-#pragma unroll
-            for (int m = 0; m < NT; ++m) asm volatile("" :: "v"(acc[m]));
-            if (inside && q == 0) { out[pix] = acc[0][0]; var_out[pix] = 0.f; sum_sim[pix] = 0.f; max_cost[pix] = rm; }
-            continue;
-        }
-#endif
         float mx, S, mu, var;
         const float mu_in = (MODE == MODE_VAR && inside) ? disparity[pix] : 0.f;
         softmax_passes<NT, MODE, 0>(acc, NT, D, dl, smem, 0, 0, 0, mu_in, mx, S, mu, var);
@@ -650,9 +617,6 @@ __device__ __forceinline__ void spamat_fwd_segment(
     const float mark = marker ? sum_sim[(size_t)row * W + (size_t)seg * (XT * 16)] : -1.0f;
     if (marker && !(mark < 0.f))
         return;
-#if DECNET_ABLATE == 8      // timing-only: launch + marker round trip
-    return;
-#endif
     if constexpr (KQ == 2) {
         // marker == 2 (whole rows per workgroup): a row the sparse-row kernel handed over may still have <= 512 active
         // pixels per side (densities 0.25-0.5 at stage 3) -- this workgroup runs the same sparse-row algorithm on it,
@@ -793,10 +757,6 @@ __device__ __forceinline__ void spamat_fwd_segment(
         const int validL = min(SW, W - xs);
         const int validR = min(W, xs + SW) - max(0, xs - HALO);
         compact = allow_compact && ((long)nL * nR * 100 < (long)validL * validR * compact_pct);
-#if DECNET_ABLATE == 9      // timing-only: + first-half loads requested, mask phase, counts
-        if (tid == 0 && d16_pre[0].x == 1.2345f) out[0] = 0.f;
-        return;
-#endif
         if (!compact) {
             // two passes over half the segment each: both views as bf16 terms need 96 bytes of LDS per pixel and
             // channel group, and the segment partition (= the number of workgroups of a marker launch, the
@@ -805,7 +765,7 @@ __device__ __forceinline__ void spamat_fwd_segment(
             dense16_body<NT, MODE, (KQ + 1) / 2, true>(reinterpret_cast<int *>(Rs), BX, LM, smem, lrow, rrow, disparity, out,
                                                        var_out, sum_sim, max_cost, plane, rowpix, C, W, D, xs, xta, xta * 16,
                                                        HALO, HALO + xta * 16, d16_pre);
-            if (DECNET_ABLATE != 10 && xtb > 0 && xs + xta * 16 < W) {
+            if (xtb > 0 && xs + xta * 16 < W) {
                 __syncthreads();
                 dense16_body<NT, MODE, (KQ + 1) / 2>(reinterpret_cast<int *>(Rs), BX + xta * 16, LM + xta * 16, smem, lrow,
                                                      rrow, disparity, out, var_out, sum_sim, max_cost, plane, rowpix, C,
@@ -846,9 +806,6 @@ __device__ __forceinline__ void spamat_fwd_segment(
         for (int c = tid; c < lo.Cq; c += THREADS) Rs[c * RP + RP - 1] = 0.f;    // zero column
     }
     __syncthreads();
-#if DECNET_ABLATE == 5      // timing-only: mask + R staging only
-    return;
-#endif
 
     const int validL = min(SW, W - xs);
     const int validR = min(W, xs + SW) - max(0, xs - HALO);
@@ -929,9 +886,6 @@ __device__ __forceinline__ void spamat_fwd_segment(
             for (int m = 0; m < NT; ++m) {
                 if (m < nact) {
                     f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#if DECNET_ABLATE == 1 || DECNET_ABLATE == 3
-                    a4 = f32x4{ap[-16 * m], ap[(4 * RP) - 16 * m], bcur[0], bcur[KB - 1]};
-#else
                     // accumulate on top of the right-mask bias (0 / -1e30 per right pixel = tile row):
                     // 0 + x is exact and -1e30 + x == -1e30, so this equals adding the bias afterwards
                     if (NT > 8) asm volatile("" ::: "memory");   // keep the 15 bias reads from being hoisted together
@@ -949,18 +903,9 @@ __device__ __forceinline__ void spamat_fwd_segment(
                             a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * RP - 16 * m], lv, a4, 0, 0, 0);
                         }
                     }
-#endif
                     acc[m] = a4;
                 }
             }
-#if DECNET_ABLATE == 2 || DECNET_ABLATE == 3
-            {
-#pragma unroll
-                for (int m = 0; m < NT; ++m) if (m < nact) asm volatile("" :: "v"(acc[m]));
-                if (inside && q == 0) { out[pix] = 0.f; var_out[pix] = 0.f; sum_sim[pix] = 0.f; max_cost[pix] = rm; }
-                continue;
-            }
-#endif
             float mx, S, mu, var;
             const float mu_in = (MODE == MODE_VAR && inside) ? disparity[pix] : 0.f;
             softmax_passes<NT, MODE, 0>(acc, nact, D, dl, smem, lo.offBX + (HALO + xt * 16) + 4 * q, 0, 0, mu_in, mx, S, mu, var);
@@ -1041,9 +986,6 @@ __device__ __forceinline__ void spamat_fwd_segment(
         }
     }
 
-#if DECNET_ABLATE == 4      // timing-only: staging + compaction + zero fill, no matching
-    return;
-#endif
     const int ngroups = (SW + S - 1) / S;
     for (int g = wave; g < ngroups; g += NWAVE) {
         const int gx = g * S;
@@ -1129,7 +1071,7 @@ __global__ __launch_bounds__(THREADS, (KQ > 6 ? 2 : 4)) void spamat_fwd_mfma(
 //      softmax passes of the compact path above (d from the index lists)
 // Rows that are not sparse enough are left to spamat_fwd_mfma, launched right after with
 // marker = 1: this kernel writes -1 to sum_sim[row start] of exactly those rows.
-constexpr int SP_THREADS = 256, SP_NWAVE = SP_THREADS / 64, SP_CAP = 256, SP_FP = SP_CAP + 16;
+constexpr int SP_THREADS = 256, SP_CAP = 256;
 // LDS words of sparse_row_body<.., KQ, PPT, NTHR, CAP, ..>
 constexpr size_t sparse_row_words(int kq, int ppt, int nthr, int cap) {
     return (size_t)(cap + 32) + 2 * (size_t)(nthr * ppt / 2 + 2) + cap + 32 + 2 * (size_t)4 * kq * (cap + 16);
@@ -1325,11 +1267,7 @@ __device__ __forceinline__ int sparse_row_body(
 
     // ---- 3. matching
     const int j = lane & 15, q = lane >> 4;
-#if DECNET_ABLATE == 6      // timing-only: masks, compaction, feature staging and the output sweep, no matching
-    for (int k = wave; k < 0; k += SP_NWAVE_) {
-#else
     for (int k = wave; k < nchunk; k += SP_NWAVE_) {
-#endif
         const int e1 = nL;
         for (int e = 16 * k; e < min(16 * k + 16, nL); e += 16) {      // (one trip: the loop shape the register allocator
             const int xa = __builtin_amdgcn_readfirstlane(XL[e]);     //  handled without spilling)
@@ -1490,19 +1428,17 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
     const int segs = ceil_div(xt_row, XT);
     dim3 block(THREADS);
     // rows go through the compaction path when fewer than compact_pct % of their candidate pairs are active
-    // (DECNET_SPAMAT_COMPACT_PCT; 80 in round 1 -- but the dense path is faster down to ~35 %, measured)
-    static const int compact_pct = [] { const char *e = getenv("DECNET_SPAMAT_COMPACT_PCT"); return e ? atoi(e) : 35; }();
+    // (80 in round 1 -- but the dense path is faster down to ~35 %, measured)
+    constexpr int compact_pct = 35;
     // ... and through the sparse-row algorithm (spamat_fwd_sparse, and the MID_CAP-slot body behind its -2 marker) below
     // sparse_pct %: with chunks of 16 active pixels that algorithm beats the dense path up to ~45 % (stage 3, density
-    // 0.6 = 36 % of the pairs: 0.30 vs 0.42 ms; DECNET_SPAMAT_SPARSE_PCT)
-    static const int sparse_pct = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE_PCT"); return e ? atoi(e) : 45; }();
+    // 0.6 = 36 % of the pairs: 0.30 vs 0.42 ms)
+    constexpr int sparse_pct = 45;
     dim3 grid((unsigned)((size_t)B * H * segs));
     // sparse rows first (KQ > 0: C <= 24; rows of <= 2048 pixels), the rest by the marker launch
-    static const int sparse_off = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 0; }();
     // (C = 24, stage 2: rows are short and in practice 40-100 % dense -- there the sparse-row pre-launch costs 6 us
-    // of a 57 us pass and only wins below ~20 % density; DECNET_SPAMAT_SPARSE=2 switches it on for C <= 24 too)
-    static const int sparse_c24 = [] { const char *e = getenv("DECNET_SPAMAT_SPARSE"); return e && atoi(e) == 2; }();
-    int marker = allow_compact && !sparse_off && (KQ == 2 || (KQ == 6 && sparse_c24)) && W <= 2048;
+    // of a 57 us pass and only wins below ~20 % density: C <= 8 only)
+    int marker = allow_compact && KQ == 2 && W <= 2048;
     // rows of 257-512 active pixels per side: the sparse-row algorithm inside the band kernel's workgroup (whole rows
     // per workgroup only; DECNET_SPAMAT_MID=0 switches it off)
     // DECNET_SPAMAT_MID=0 switches it off (a separate 256-thread launch for these rows was measured slower: tools/experiments)
@@ -1520,9 +1456,6 @@ int launch_nt(int mode, const float *ref, const float *tar, const float *rmask, 
             if (need > lds_launch) lds_launch = need;
         }
     }
-#ifdef DECNET_DEV_STAGE3       // occupancy experiments: DECNET_SPAMAT_LDS_PAD_KB more LDS per band-kernel workgroup
-    { const char *e = getenv("DECNET_SPAMAT_LDS_PAD_KB"); if (e) lds_launch += (size_t)atoi(e) * 1024; }
-#endif
     if constexpr (KQ > 0 && KQ <= 6) if (marker) {
         const int ppt = W <= 1024 ? 4 : 8;
         const size_t slds = 4 * sparse_row_words(KQ, ppt, SP_THREADS, SP_CAP);
@@ -1585,19 +1518,11 @@ int launch_kq(int mode, const float *ref, const float *tar, const float *rmask, 
 #define GO(K)                                                                                      \
     return launch_nt<NT, K>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim,        \
                             max_cost, B, C, H, W, D, allow_compact, mbits, stream)
-#ifdef DECNET_DEV_STAGE2               // experiment builds: the stage-2 instantiation only
-    if (C <= 24 && C > 20) GO(6);
-    return DECNET_ERR_UNSUPPORTED;
-#endif
     if (C <= 8 && C > 4) GO(2);        // stage 3 of the shipped network (C = 8)
-#ifdef DECNET_DEV_STAGE3               // tools/dev_spamat.sh: the stage-3 instantiation only (seconds to compile)
-    return DECNET_ERR_UNSUPPORTED;
-#else
     if (C <= 24 && C > 20) GO(6);      // stage 2 (C = 24)
     if (C <= 72 && C > 68) GO(18);     // stage 1 (C = 72)
     GO(0);                             // anything else: runtime K loop, left operand read straight
                                        // from L2/HBM per K-step
-#endif
 #undef GO
 }
 
@@ -1616,14 +1541,6 @@ int decnet_mfma_forward(int mode, const float *ref, const float *tar, const floa
 #define GO(N)                                                                                     \
     return launch_kq<N>(mode, ref, tar, rmask, tmask, disparity, out, var_out, sum_sim, max_cost, \
                         B, C, H, W, D, allow_compact, mbits, stream)
-#ifdef DECNET_DEV_STAGE2        // experiment builds: the stage-2 instantiation only
-    if (need <= 6 && need > 3) GO(6);
-    return DECNET_ERR_UNSUPPORTED;
-#endif
-#ifdef DECNET_DEV_STAGE3        // tools/dev_spamat.sh: the stage-3 instantiation only
-    if (need <= 15 && need > 11) GO(15);
-    return DECNET_ERR_UNSUPPORTED;
-#else
     if (need <= 3) GO(3);       // D <= 32   (stage 1: 24, 30)
     if (need <= 6) GO(6);       // D <= 80   (stage 2: 72)
     if (need <= 8) GO(8);       // D <= 112  (stage 2 at max_disp 270: 90)
@@ -1631,6 +1548,5 @@ int decnet_mfma_forward(int mode, const float *ref, const float *tar, const floa
     if (need <= 15) GO(15);     // D <= 224  (stage 3: 216)
     if (need <= 18) GO(18);     // D <= 272  (stage 3 at max_disp 270)
     return DECNET_ERR_UNSUPPORTED;
-#endif
 #undef GO
 }

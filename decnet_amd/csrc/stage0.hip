@@ -19,9 +19,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef DECNET_CONV_ABLATE
-#define DECNET_CONV_ABLATE 0   // diagnostic builds only (results wrong by construction):
-#endif                         // 1 no HBM/L2 prefetch, 2 no MFMA, 3 no per-step barrier, 4 no LDS staging
 
 namespace {
 
@@ -251,233 +248,28 @@ __global__ __launch_bounds__(WM * 128) void conv3d_k3_igemm(
     const int b_col0 = kq * B_PITCH + wn * (CONV_BN / 2) + i16;
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
-#if DECNET_CONV_ABLATE != 1 && DECNET_CONV_ABLATE < 5
         if (s + 1 < nstep) prefetch(s + 1);
-#endif
         const float *a = As + buf * A_TILE + a_row0;
         const float *b = Bs + buf * B_TILE + b_col0;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             float av[TM], bv[TN];
 #pragma unroll
-#if DECNET_CONV_ABLATE == 5
-            for (int i = 0; i < TM; ++i) av[i] = (float)(kk + i + s);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = (float)(kk - j);
-#else
             for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * A_PITCH + kk * 4];
 #pragma unroll
             for (int j = 0; j < TN; ++j) bv[j] = b[kk * 4 * B_PITCH + j * 16];
-#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-#if DECNET_CONV_ABLATE == 2
-                    acc[i][j][0] += av[i] + bv[j];
-#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-#endif
         }
-#if DECNET_CONV_ABLATE != 4 && DECNET_CONV_ABLATE < 5
         if (s + 1 < nstep) stage(buf ^ 1);
-#endif
-#if DECNET_CONV_ABLATE != 3 && DECNET_CONV_ABLATE < 5
         __syncthreads();
-#endif
     }
 
     // epilogue: BN (folded scale/shift) -> ReLU -> + residual.  C/D layout of 16x16x4:
     // col = lane & 15, row = 4 * (lane >> 4) + r.
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int co = wn * (CONV_BN / 2) + j * 16 + i16;
-        if (co >= Co) continue;
-        float sc = scale[co], sh = shift[co];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int m = m_block + wm * 48 + i * 16 + kq * 4 + r;
-                if (m >= M) continue;
-                float v = fmaf(acc[i][j][r], sc, sh);
-                if (relu) v = fmaxf(v, 0.f);
-                size_t o = (size_t)m * Co + co;
-                if (residual) v += residual[o];
-                y[o] = v;
-            }
-    }
-}
-
-// ---------------------- Conv3d implicit GEMM, operands by LDS-DMA ----------------------
-// Same tiling as conv3d_k3_igemm (WM x 2 waves, 48 x 112 per wave, BK = 24), but the A and B
-// tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write,
-// no wait on the loads before the step's barrier.  An LDS-DMA wave-instruction writes 64 x 16 B
-// contiguously, so the tiles are stored unpadded and bank conflicts are removed by choosing WHICH
-// 16-byte chunk each lane fetches (the swizzle lives in the source address, the fragment reads
-// apply the same involution):
-//   A[row][24]  slot = chunk ^ ((row >> 3) & 1); fragments are read as 8-byte pairs, so MFMA step
-//               t = 2p+e of a chunk pair uses K element 8p + 2*kq + e for lane quad kq
-//   B[k][224]   slot = chunk ^ (4 * ((k >> 1) & 1))  (= 4 * (kq & 1) for the K order above)
-// Padding taps and the M tail are zero-filled by the bounds check of the buffer load itself
-// (tools/ubench/lds_dma_oob.hip verifies that out-of-range lanes write zeros on gfx950).
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
-
-template <int WM, int NBUF>
-__global__ __launch_bounds__(WM * 128) void conv3d_k3_igemm_dma(
-    const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ scale,
-    const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ y,
-    int D, int H, int W, int Ci, int Co, int relu, int M, int x_bytes, int w_bytes) {
-    constexpr int BK = 24, NWAVES = WM * 2, BM = WM * 48, TM = 3, TN = 7;
-    constexpr int A_TILE = BM * BK, B_TILE = BK * CONV_BN, TILE = A_TILE + B_TILE;   // floats
-    constexpr int NA = A_TILE / 256, NB = B_TILE / 256, NI = NA + NB;   // 1 KiB DMA instructions
-    constexpr int T = (NI + NWAVES - 1) / NWAVES;                       // per wave
-    constexpr int OOB = 0x7fffffff;
-    static_assert(A_TILE % 256 == 0 && B_TILE % 256 == 0, "tiles are whole DMA instructions");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];         // [NBUF][TILE]
-
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, w_bytes, 0x00020000);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // DMA instructions this wave issues per tile (wave-uniform): n = wave, wave+NWAVES, ... < NI
-    const int my_dma = (NI - wave + NWAVES - 1) / NWAVES;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int m_block = blockIdx.x * BM;
-
-    // this wave's DMA instructions n = wave + t*NWAVES: per-lane source offset + tap validity
-    int d_off[T], d_tap[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int n = wave + t * NWAVES;
-        int off = OOB, bits = 0;
-        if (n < NA) {
-            int g = n * 64 + lane, row = g / 6, cs = g - row * 6;
-            int c = cs ^ ((row >> 3) & 1);
-            int m = m_block + row;
-            if (m < M) {
-                int xx = m % W; int q = m / W;
-                int yy = q % H; q /= H;
-                int dd = q % D;
-                off = (m * Ci + 4 * c) * 4;
-                for (int tap = 0; tap < 27; ++tap) {
-                    int zd = dd + tap / 9 - 1, zy = yy + (tap / 3) % 3 - 1, zx = xx + tap % 3 - 1;
-                    if ((unsigned)zd < (unsigned)D && (unsigned)zy < (unsigned)H && (unsigned)zx < (unsigned)W)
-                        bits |= 1 << tap;
-                }
-            }
-        } else if (n < NI) {
-            int g = (n - NA) * 64 + lane, k = g / 56, cs = g - k * 56;
-            int c = cs ^ (4 * ((k >> 1) & 1));
-            off = (k * CONV_BN + 4 * c) * 4;
-            bits = 0x7ffffff;
-        }
-        d_off[t] = off;
-        d_tap[t] = bits;
-    }
-
-    const int nchunk = Ci / BK;                    // host guarantees Ci % 24 == 0
-    const int nstep = 27 * nchunk;
-    auto dma = [&](int s, int buf) {
-        int tap = s / nchunk, ci0 = (s - tap * nchunk) * BK;
-        int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
-        int a_step = (((kd * H + kh) * W + kw) * Ci + ci0) * 4;
-        int b_step = (tap * Ci + ci0) * CONV_BN * 4;
-        float *base = smem + buf * TILE;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int n = wave + t * NWAVES;       // wave-uniform
-            if (n < NI) {
-                const bool isA = n < NA;
-                int voff = ((d_tap[t] >> tap) & 1) ? d_off[t] + (isA ? a_step : b_step) : OOB;
-                if (isA)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(base + n * 256), 16, voff, 0, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, LDS_PTR(base + n * 256), 16, voff, 0, 0, 0);
-            }
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment addresses (floats, relative to the buffer base)
-    int a_addr[TM];        // + 8*p floats per chunk pair
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int row = wm * 48 + i * 16 + i16;
-        // chunk 2p + (kq>>1), slot = chunk ^ ((row>>3)&1), float pair kq&1 inside the chunk
-        a_addr[i] = row * BK + 4 * ((kq >> 1) ^ ((row >> 3) & 1)) + 2 * (kq & 1);
-    }
-    int b_addr[TN];        // + k*224 floats, k = 8p + 2kq + e
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int n = wn * (CONV_BN / 2) + j * 16 + i16;
-        b_addr[j] = A_TILE + 2 * kq * CONV_BN + (((n >> 2) ^ (4 * (kq & 1))) << 2) + (n & 3);
-    }
-
-    // Pipeline: NBUF LDS buffers, tiles s+1 .. s+NBUF-1 in flight while tile s is on the MFMAs.
-    // The barrier that ends step s only needs tile s+1 (issued NBUF-2 steps ago when NBUF = 3):
-    // a COUNTED vmcnt leaves the younger DMAs in flight, and a raw s_barrier is used because
-    // __syncthreads() would drain them (vmcnt(0)).
-    auto wait_tiles_in_flight = [&](int tiles) {           // wave-uniform switch on my_dma * tiles
-        int nn = my_dma * tiles;
-        if (nn == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nn <= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (nn == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (nn == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (nn == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (nn == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (nn == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    };
-#pragma unroll
-    for (int s0 = 0; s0 < NBUF - 1; ++s0)
-        if (s0 < nstep) dma(s0, s0);
-    wait_tiles_in_flight(nstep > 1 ? NBUF - 2 : 0);
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    for (int s = 0; s < nstep; ++s) {
-        int nb = buf + NBUF - 1;
-        if (nb >= NBUF) nb -= NBUF;
-        if (s + NBUF - 1 < nstep) dma(s + NBUF - 1, nb);   // that buffer was read in step s-1
-        const float *base = smem + buf * TILE;
-#pragma unroll
-        for (int p = 0; p < BK / 8; ++p) {
-            float2 av[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                av[i] = *reinterpret_cast<const float2 *>(base + a_addr[i] + 8 * p);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float bv[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = base[b_addr[j] + (8 * p + e) * CONV_BN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(e ? av[i].y : av[i].x, bv[j],
-                                                                         acc[i][j], 0, 0, 0);
-            }
-        }
-        // tile s+1 must have landed (all but the NBUF-2 youngest tiles of this wave), then
-        // everyone must be done reading buf before it is overwritten in the next step
-        int younger = nstep - 1 - (s + 1);                 // tiles issued after tile s+1
-        if (younger > NBUF - 2) younger = NBUF - 2;
-        if (younger < 0) younger = 0;
-        wait_tiles_in_flight(younger);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        buf = buf + 1 == NBUF ? 0 : buf + 1;
-    }
-
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int co = wn * (CONV_BN / 2) + j * 16 + i16;
@@ -602,24 +394,6 @@ int launch_conv(const float *x, const float *wp, const float *scale, const float
     return decnet_launch_status();
 }
 
-template <int WM, int NBUF>
-int launch_conv_dma(const float *x, const float *wp, const float *scale, const float *shift,
-                    const float *residual, float *y, int D, int H, int W, int Ci, int Co, int relu,
-                    int M, hipStream_t stream) {
-    constexpr int BM = WM * 48;
-    size_t lds = 4 * (size_t)NBUF * (BM * 24 + 24 * CONV_BN);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv3d_k3_igemm_dma<WM, NBUF>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    int x_bytes = (int)((size_t)M * Ci * 4), w_bytes = 27 * Ci * CONV_BN * 4;
-    hipLaunchKernelGGL((conv3d_k3_igemm_dma<WM, NBUF>), dim3(ceil_div(M, BM)), dim3(WM * 128), lds, stream,
-                       x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, x_bytes, w_bytes);
-    return decnet_launch_status();
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // Last Conv3dUnit (Ci -> 1) in two passes that read the activations ONCE (the one-kernel version
 // above gathers every input row 27 times):
@@ -740,8 +514,7 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
         return DECNET_ERR_BAD_SHAPE;
     // channel groups of <= 128, equal sizes: 216 -> 2 x 108 with 4 disparities per workgroup measured best
     // (0.031 ms; one workgroup per row with all 216 channels and 8 disparities: 0.046 ms; 4 x 54: 0.044 ms)
-    static const int cg_env = [] { const char *e = getenv("DECNET_COSTVOL_CGROUP"); return e ? atoi(e) : 0; }();
-    const int groups = cg_env > 0 ? ceil_div(C, cg_env) : ceil_div(C, 128), cgn = ceil_div(C, groups);
+    const int groups = ceil_div(C, 128), cgn = ceil_div(C, groups);
     size_t lds = (size_t)3 * cgn * (W | 1) * 4;
     if (lds > DECNET_LDS_BYTES - 1024) return DECNET_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
@@ -751,10 +524,8 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
     }
     // disparities per workgroup: the row staging (3 x C x W floats, three dependent load batches) is the
     // expensive part, so a workgroup keeps its rows for as many d as still leaves >= ~1 workgroup per CU
-    static const int dc_env = [] { const char *e = getenv("DECNET_COSTVOL_DCHUNK"); return e ? atoi(e) : 0; }();
     int dchunk = 1;
     while (dchunk < D && (long)B * H * ceil_div(C, cgn) * ceil_div(D, 2 * dchunk) >= 512) dchunk *= 2;
-    if (dc_env > 0) dchunk = dc_env;
     hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H), (unsigned)ceil_div(D, dchunk),
                                                (unsigned)ceil_div(C, cgn)),
                        dim3(512), lds, (hipStream_t)stream, left, right, cost, C, H, W, D, dchunk, cgn);
@@ -790,25 +561,6 @@ int decnet_conv3d_bn_act(const float *x, const float *wp, const float *scale, co
     // two waves per SIMD)
     long r192 = (ceil_div(M, 192) + 255) / 256 * 192, r96 = (ceil_div(M, 96) + 255) / 256 * 96;
     hipStream_t s = (hipStream_t)stream;
-    static const int pinned = [] {          // DECNET_CONV_TILE=192x36|192x24|96x24 (A/B benchmarks)
-        const char *e = getenv("DECNET_CONV_TILE");
-        if (!e) return 0;
-        return !strcmp(e, "192x36") ? 1 : !strcmp(e, "192x24") ? 2 : !strcmp(e, "96x24") ? 3
-             : !strcmp(e, "dma192") ? 4 : !strcmp(e, "dma96") ? 5 : !strcmp(e, "dma192x3") ? 6
-             : !strcmp(e, "dma96x3") ? 7 : 0;
-    }();
-    if (pinned == 4 && Ci % 24 == 0)
-        return launch_conv_dma<4, 2>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-    if (pinned == 5 && Ci % 24 == 0)
-        return launch_conv_dma<2, 2>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-    if (pinned == 6 && Ci % 24 == 0)
-        return launch_conv_dma<4, 3>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-    if (pinned == 7 && Ci % 24 == 0)
-        return launch_conv_dma<2, 3>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-    if (pinned == 1 && Ci % 36 == 0)
-        return launch_conv<4, 36>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-    if (pinned == 2) return launch_conv<4, 24>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
-    if (pinned == 3) return launch_conv<2, 24>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);
     if (r192 <= r96) {
         if (Ci % 36 == 0)
             return launch_conv<4, 36>(x, wp, scale, shift, residual, y, D, H, W, Ci, Co, relu, M, s);

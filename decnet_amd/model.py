@@ -81,22 +81,22 @@ class Unit(nn.Module):
         c = self.conv
         # many channels: the bf16x3 matrix-core kernel (csrc/conv2d_mfma.hip) where the image gives it enough
         # workgroups (>= 4096 pixels, e.g. the 60 x 108 level; at 20 x 36 the library's kernels win)
-        # (round 3: also 9..23 outputs from >= 16 inputs.  The 20 x 36 level stays on the library: measured with
-        # DECNET_MFMA_MIN_PIXELS=512, 649 -> 81 takes 0.265 ms here against 0.107 ms, the 864 / 432 -> 216 1 x 1 layers
+        # (round 3: also 9..23 outputs from >= 16 inputs.  The 20 x 36 level stays on the library: measured with the
+        # pixel threshold at 512, 649 -> 81 takes 0.265 ms here against 0.107 ms, the 864 / 432 -> 216 1 x 1 layers
         # 0.131 / 0.081 against 0.053 / 0.042 -- 144 workgroups of a K = 5841 reduction each do not fill 256 CUs)
         if (isinstance(c, nn.Conv2d) and
-                (c.out_channels >= int(os.environ.get("DECNET_MFMA_MIN_COUT", "9")) or c.in_channels >= 48) and
+                (c.out_channels >= 9 or c.in_channels >= 48) and
                 c.in_channels >= 16 and c.kernel_size in ((1, 1), (3, 3)) and
                 c.stride == (1, 1) and c.dilation[0] == c.dilation[1] and c.groups == 1 and c.padding_mode == "zeros" and
                 c.padding == (c.dilation[0] * (c.kernel_size[0] // 2),) * 2 and
-                x.shape[-1] * x.shape[-2] >= int(os.environ.get("DECNET_MFMA_MIN_PIXELS", "4096")) and
+                x.shape[-1] * x.shape[-2] >= 4096 and
                 c.dilation[0] <= 4 and os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma"
         # Conv2d k 3, stride 3, padding 1 with more than 24 outputs: space-to-depth + the same kernel as a 1 x 1 convolution
         if (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (1, 1) and
                 c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros" and c.out_channels > 24 and
                 c.in_channels >= 8 and x.shape[-1] * x.shape[-2] >= 4608 and
-                os.environ.get("DECNET_CONV2D_MFMA", "1") == "1" and os.environ.get("DECNET_MFMA_S3", "1") == "1"):
+                os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma_s3"
         # transposed convolution k = 3, stride 3 with more than 8 output channels: the same kernel, as a 1 x 1 convolution
         # to 9 Cout channels with a pixel-shuffle store
@@ -107,10 +107,9 @@ class Unit(nn.Module):
                 os.environ.get("DECNET_CONV2D_MFMA", "1") == "1"):
             return "mfma_deconv"
         # the few-channel kernels at every size (at 60 x 108 and 20 x 36 they do not fill the chip, but one launch
-        # replaces the library's convolution + layout transposes + bias / ReLU passes); DECNET_SMALL_MIN_PIXELS=16384
-        # restores round 2's threshold
+        # replaces the library's convolution + layout transposes + bias / ReLU passes)
         up = 9 if isinstance(c, nn.ConvTranspose2d) else 1
-        if x.shape[-1] * x.shape[-2] * up < int(os.environ.get("DECNET_SMALL_MIN_PIXELS", "256")):
+        if x.shape[-1] * x.shape[-2] * up < 256:
             return None
         if (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (3, 3) and c.padding == (1, 1) and
                 c.dilation == (1, 1) and c.groups == 1 and c.padding_mode == "zeros" and c.out_channels <= 24):
@@ -357,8 +356,7 @@ class Unit(nn.Module):
             _tally(self, "library", x)
         if isinstance(x, (tuple, list)):
             x = torch.cat(tuple(x), 1)
-        if (self.bn is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda and
-                os.environ.get("DECNET_FOLD_BN", "1") == "1"):
+        if self.bn is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda:
             w, b = self._folded_torch()
             c = self.conv
             if isinstance(c, nn.ConvTranspose2d):
@@ -682,8 +680,7 @@ class SoftAttention(nn.Module):
         parts = (fea, dense.unsqueeze(1), sparse.unsqueeze(1), mask.unsqueeze(1), var.unsqueeze(1))
         u0, u1, u2 = self.conv[0], self.conv[1], self.conv[2]
         k0 = u0._hip_kind(parts)
-        if (k0 in ("conv", "mfma") and u2.conv.out_channels == 1 and not u2.relu and
-                os.environ.get("DECNET_FUSE_TAILS", "1") == "1"):
+        if k0 in ("conv", "mfma") and u2.conv.out_channels == 1 and not u2.relu:
             if k0 == "conv":
                 t = u0._forward_hip(parts, "conv", neg_last=True)
             else:                                       # many input channels (1/9, 1/3 resolution): matrix-core kernel
@@ -734,7 +731,7 @@ class Refinement(nn.Module):
     def forward(self, left, right, disp):
         x = (left, warp_by_disparity(right, disp), disp.unsqueeze(1))
         last = self.conv[-1]
-        if os.environ.get("DECNET_FUSE_TAILS", "1") == "1" and last.conv.out_channels == 1:
+        if last.conv.out_channels == 1:
             t = x
             for u in list(self.conv)[:-1]:
                 t = u(t)
@@ -796,7 +793,7 @@ class SparseDenseNetRefinementMask(nn.Module):
         if self.training:
             raise NotImplementedError("inference only: call .eval() (SURVEY.md S11)")
         f2 = None
-        if left.is_cuda and left.shape == right.shape and os.environ.get("DECNET_FEAT_BATCH", "1") == "1":
+        if left.is_cuda and left.shape == right.shape:
             # both views in one pass (per-sample ops, eval BN: same result; the 1/9 and 1/27 layers
             # are too small at B pairs to fill 256 CUs)
             f2 = self.feature_extractor(left, right)
@@ -835,7 +832,7 @@ class SparseDenseNetRefinementMask(nn.Module):
             lmask, rmask, lbits, rbits = masks
             D = max_disp_of(stage)
             res = None
-            if (lbits is not None and rbits is not None and D <= 272 and os.environ.get("DECNET_SPAMAT_BITS", "1") == "1"):
+            if lbits is not None and rbits is not None and os.environ.get("DECNET_SPAMAT_BITS", "1") == "1":
                 try:
                     res = spamatvar_forward_bits(L.contiguous(), R.contiguous(), lbits, rbits, D, out=out)
                 except DecnetHipError as e:             # shapes only the float-mask entry's fallback kernels cover
@@ -848,10 +845,10 @@ class SparseDenseNetRefinementMask(nn.Module):
         # The masks and the SpaMat / SpaVar pass of EVERY level depend on the feature maps only -- not on the coarser
         # level's prediction (reference :148-192).  On the GPU they run ahead on a second HIP stream, beside the stage-0
         # Conv3d stack and the DynamicUpsampling convolutions (fp32-issue- and HBM-bound kernels beside bf16 matrix-core
-        # GEMMs); the main stream picks a level's results up behind an event.  DECNET_OVERLAP=0: everything in order.
+        # GEMMs); the main stream picks a level's results up behind an event.
         stages = [st for st in range(1, nstage) if st < self.skip_stage_id]
         ahead = {}
-        overlap = left.is_cuda and os.environ.get("DECNET_OVERLAP", "1") == "1" and stages
+        overlap = left.is_cuda and stages
         if overlap:
             cur = torch.cuda.current_stream(left.device)
             side = _side_stream(left.device)

@@ -315,7 +315,7 @@ class CostRegNetNoDown(nn.Module):
             p = P[7]
             regp = reg.data_ptr() if reg is not None else None
             need = L.decnet_conv3d_cout1_workspace_floats(B, D, H, W)
-            if p["Ci"] <= 256 and D <= 256 and os.environ.get("DECNET_COUT1", "gemm") != "gather":
+            if p["Ci"] <= 256 and D <= 256:
                 t = a if a.numel() >= need else self._scratch(dev, need)     # a is free by now
                 rc = L.decnet_conv3d_cout1_softargmax_ws(c.data_ptr(), p["w"].data_ptr(), p["scale"], p["shift"],
                                                          regp, pred.data_ptr(), t.data_ptr(), B, D, H, W,

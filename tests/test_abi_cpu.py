@@ -96,3 +96,23 @@ def test_conv_algo_choice_and_sizes(lib, monkeypatch):
         tiles = 8 * -(-8 // od) * -(-20 // oh) * -(-36 // oh)
         assert lib.decnet_conv3d_wino_workspace_floats(8, 8, 20, 36, 216, 216, v) == pts * tiles * (224 + 224)
     assert lib.decnet_conv3d_wino_weight_floats(216, 3) == 0
+
+
+def test_hip_lib_override_fails_loudly_when_the_file_is_missing(tmp_path):
+    """DECNET_HIP_LIB points the loader at another build of the library (tools/dev_obj.sh experiment builds); a path that
+    does not exist is an error at first use, never a silent fallback to the default build or to the CPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from decnet_amd import _lib\n"
+            "try:\n"
+            "    _lib.lib()\n"
+            "except Exception as e:\n"
+            "    print('RAISED', type(e).__name__)\n"
+            "else:\n"
+            "    print('LOADED')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DECNET_HIP_LIB=str(tmp_path / "nope.so")),
+                       capture_output=True, text=True, timeout=120)
+    assert "RAISED" in r.stdout and "LOADED" not in r.stdout, r.stdout + r.stderr

@@ -139,3 +139,14 @@ def test_data_parallel_replicas_share_nothing_mutable():
         got = parallel_apply(reps, [(left, right), (left2, right2)])
     for w, g in zip(want, got):
         assert float((w - g[-1]).abs().max()) < 1e-4
+
+
+def test_e2e_with_the_library_trunk():
+    """DECNET_CONV2D=torch: every 2-D layer through torch's own convolution / batch-norm calls (the reference's arithmetic;
+    the SpaMat / SpaVar and stage-0 kernels stay) -- the knob the accuracy comparisons of tests/test_inputdata_gpu.py quote.
+    One leg in a child process (the knob is read per layer call, the child keeps the rest of this process unaffected)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x",
+                        "-k", "test_e2e_against_reference_graph"], env=dict(os.environ, DECNET_CONV2D="torch"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Experiment build: recompile ONE csrc/*.hip with extra flags and link it with the regular build's other objects
 # into tools/ubench/libdecnet_dev_<tag>.so (use with DECNET_HIP_LIB=...).
-#   tools/dev_obj.sh x1 conv2d_mfma -DDECNET_C2M_ABLATE=1
+#   tools/dev_obj.sh x1 conv2d_mfma -DSOME_EXPERIMENT=1
 set -e
 cd "$(dirname "$0")/.."
 TAG=$1; NAME=$2; shift 2
