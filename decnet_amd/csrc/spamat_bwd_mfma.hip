@@ -63,7 +63,8 @@ struct BLayout {
 };
 // cq: channel rows staged = 4 * KQ of the instantiation (>= C): the cost MFMAs read all of them (against zero own
 // operands beyond C), so the rows between C and 4 KQ must exist and hold zeros, not whatever LDS held before
-__host__ __device__ inline BLayout make_blayout(int cq, int NT, int XT, int npl) {
+// nown: planes of per-OWN-pixel scalars behind the other side's planes (SW entries each)
+__host__ __device__ inline BLayout make_blayout(int cq, int NT, int XT, int npl, int nown) {
     BLayout l;
     l.SW = XT * 16;
     l.HALO = (NT - 1) * 16;
@@ -71,9 +72,15 @@ __host__ __device__ inline BLayout make_blayout(int cq, int NT, int XT, int npl)
     l.OP = ((l.OW + 63) & ~63) + 4;
     l.Cq = cq;
     l.offP = l.Cq * l.OP;
-    l.total = l.offP + npl * l.OW;
+    l.total = l.offP + npl * l.OW + nown * l.SW;
     return l;
 }
+// own planes.  SIDE 0 (lanes own left pixels): 0 -max*log2e (-1e30 where the left mask is off: every weight 0), 1 out,
+// 2 g/S (0 where the mask is off), 3 mu (SpaVar).  SIDE 1 (lanes own right pixels): 0 the right mask.
+// Round 6, from the ISA: these scalars were per-lane global loads inside the tile loop -- own mask, max, out in front of the
+// band tiles (one exposed round trip per wave-tile) and mask / g / S again for the four pixels of the epilogue, each pair
+// behind its own `s_waitcnt vmcnt(0)`: eight serial round trips per wave-tile, more than the tile's arithmetic at stage 2.
+__host__ __device__ constexpr int bwd_nown(int side, bool var) { return side == 0 ? (var ? 4 : 3) : 1; }
 
 // planes: 0 bias (0 / -1e30 of the other side's mask); SIDE 1 adds 1 -max*log2e, 2 out, 3 g/S, 4 mu
 template <int NT, bool VAR, int KQ, int SIDE>
@@ -91,12 +98,13 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
         const size_t at = ((size_t)(rw / H) * C * H + (rw % H)) * W + (size_t)sg * (XT * 16);
         if (__float_as_int(grad_own[at]) != BWD_MARK) return;
     }
-    constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
+    constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4), NOWN = bwd_nown(SIDE, VAR);
     constexpr int NCB = (4 * KQ + 15) / 16;          // 16-channel blocks of the contraction
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const BLayout lo = make_blayout(4 * KQ, NT, XT, NPL);
+    const BLayout lo = make_blayout(4 * KQ, NT, XT, NPL, NOWN);
     float *Os = smem;
     float *PL = smem + lo.offP;
+    float *OWNP = PL + NPL * lo.OW;                  // [NOWN][SW]
     const int SW = lo.SW, HALO = lo.HALO, OW = lo.OW, OP = lo.OP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,18 +226,62 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
                 if (VAR) *reinterpret_cast<float4 *>(PL + 4 * OW + j) = dd;
             }
         }
+        // the own pixels' scalars (see bwd_nown)
+        const float *own_mask = (SIDE == 0 ? rmask : tmask) + rowpix;
+        const bool alo = uniform_flag(alp && (W & 3) == 0 && (((uintptr_t)own_mask) & 15) == 0 &&
+                                      (!VAR || (((uintptr_t)disparity) & 15) == 0));
+        for (int j = tid * 4; j < SW; j += THREADS * 4) {
+            const int x = xs + j;
+            float4 mk, mx, oo, gg, ss, dd;
+            if (alo) {
+                const bool inx = x < W;
+                mk = load4_raw(own_mask, own_mask + x, inx);
+                if (SIDE == 0) {
+                    mx = load4_raw(own_mask, max_cost + rowpix + x, inx);
+                    oo = load4_raw(own_mask, out + rowpix + x, inx);
+                    gg = load4_raw(own_mask, grad_out + rowpix + x, inx);
+                    ss = load4_raw(own_mask, sum_sim + rowpix + x, inx);
+                    if (VAR) dd = load4_raw(own_mask, disparity + rowpix + x, inx);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mk = sel4(inx, mk);
+            } else {
+                mk = load4(own_mask, x, W, false);
+                if (SIDE == 0) {
+                    mx = load4(max_cost + rowpix, x, W, false);
+                    oo = load4(out + rowpix, x, W, false);
+                    gg = load4(grad_out + rowpix, x, W, false);
+                    ss = load4(sum_sim + rowpix, x, W, false);
+                    if (VAR) dd = load4(disparity + rowpix, x, W, false);
+                }
+            }
+            // (mk is 0 outside the row on both paths; the other planes are only used where mk != 0)
+            if (SIDE == 0) {
+                *reinterpret_cast<float4 *>(OWNP + j) =
+                    make_float4(mk.x != 0.f ? -mx.x * LOG2E : NEG_BIG, mk.y != 0.f ? -mx.y * LOG2E : NEG_BIG,
+                                mk.z != 0.f ? -mx.z * LOG2E : NEG_BIG, mk.w != 0.f ? -mx.w * LOG2E : NEG_BIG);
+                *reinterpret_cast<float4 *>(OWNP + SW + j) = oo;
+                *reinterpret_cast<float4 *>(OWNP + 2 * SW + j) =
+                    make_float4(mk.x != 0.f ? gg.x / ss.x : 0.f, mk.y != 0.f ? gg.y / ss.y : 0.f,
+                                mk.z != 0.f ? gg.z / ss.z : 0.f, mk.w != 0.f ? gg.w / ss.w : 0.f);
+                if (VAR) *reinterpret_cast<float4 *>(OWNP + 3 * SW + j) = dd;
+            } else {
+                *reinterpret_cast<float4 *>(OWNP + j) = mk;
+            }
+        }
     }
     __syncthreads();
 
     const int j = lane & 15, q = lane >> 4;
     const int cj = j < lo.Cq ? j : lo.Cq - 1;        // channel this lane supplies to the contraction
+    const bool al4 = (W & 3) == 0 && (((uintptr_t)grad_own) & 15) == 0;     // 16-byte stores of four pixels of a channel
+    // the own features of the NEXT tile of this wave: requested unconditionally (clamped tile, pixel and channel) and
+    // selected when they are used -- a masked load merged with a zero is waited for on the spot (see spamat_bwd_rowb)
     float bv[KQ], bcur[KQ];
     auto fetch_own = [&](int xt, float (&dst)[KQ]) {
-        const int x = xs + xt * 16 + j;
-        const bool ok = xt < XT && x < W;
+        const int x = min(xs + min(xt, XT - 1) * 16 + j, W - 1);
 #pragma unroll
-        for (int s = 0; s < KQ; ++s)
-            dst[s] = (ok && 4 * s + q < C) ? own_row[(size_t)(4 * s + q) * plane + x] : 0.f;
+        for (int s = 0; s < KQ; ++s) dst[s] = own_row[(size_t)min(4 * s + q, C - 1) * plane + x];
     };
     fetch_own(wave, bv);
 
@@ -239,17 +291,19 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
         const int x = x0 + j;
         const bool inside = x < W;
 #pragma unroll
-        for (int s = 0; s < KQ; ++s) bcur[s] = bv[s];
+        for (int s = 0; s < KQ; ++s) bcur[s] = (inside && 4 * s + q < C) ? bv[s] : 0.f;
         fetch_own(xt + NWAVE, bv);
-        // own-pixel scalars (SIDE 0: this lane's left pixel)
+        // own-pixel scalars out of the own planes.  A masked-off own pixel takes part in no candidate (its costs were
+        // never bounded by the forward's max, so exp could overflow): all its weights are forced to 0 -- SIDE 0 through
+        // its -1e30 exponent offset, SIDE 1 by the select below
         float nm_own = 0.f, out_own = 0.f, mu_own = 0.f;
-        // a masked-off own pixel takes part in no candidate (its costs were never bounded by the
-        // forward's max, so exp could overflow): all its weights are forced to 0
-        const bool own_on = inside && (SIDE == 0 ? rmask : tmask)[rowpix + (inside ? x : 0)] != 0.f;
-        if (SIDE == 0 && inside) {
-            nm_own = -max_cost[rowpix + x] * LOG2E;
-            out_own = out[rowpix + x];
-            if (VAR) mu_own = disparity[rowpix + x];
+        bool own_on = true;
+        if (SIDE == 0) {
+            nm_own = OWNP[xt * 16 + j];
+            out_own = OWNP[SW + xt * 16 + j];
+            if (VAR) mu_own = OWNP[3 * SW + xt * 16 + j];
+        } else {
+            own_on = OWNP[xt * 16 + j] != 0.f;
         }
         f32x4 gacc[NCB];
 #pragma unroll
@@ -320,38 +374,30 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
 
         // gacc[cb][r]: channel c = 16*cb + (lane & 15), own pixel x0 + 4q + r
         const int xr = x0 + 4 * q;
-        float sc[4];
-        if (SIDE == 0) {
-            // grad_ref = g * sum / S (SM_kernel.cu:193); masked-off pixels stay 0 (SpaMat.py:42)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int xx = xr + r;
-                sc[r] = (xx < W && rmask[rowpix + xx] != 0.f) ? grad_out[rowpix + xx] / sum_sim[rowpix + xx] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int xx = xr + r;
-                sc[r] = (xx < W && tmask[rowpix + xx] != 0.f) ? 1.f : 0.f;
-            }
-        }
+        // grad_ref = g * sum / S (SM_kernel.cu:193); masked-off pixels stay 0 (SpaMat.py:42)
+        const float4 s4 = *reinterpret_cast<const float4 *>(OWNP + (SIDE == 0 ? 2 * SW : 0) + xt * 16 + 4 * q);
+        const float sc[4] = {SIDE == 0 ? s4.x : (s4.x != 0.f ? 1.f : 0.f), SIDE == 0 ? s4.y : (s4.y != 0.f ? 1.f : 0.f),
+                             SIDE == 0 ? s4.z : (s4.z != 0.f ? 1.f : 0.f), SIDE == 0 ? s4.w : (s4.w != 0.f ? 1.f : 0.f)};
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int c = 16 * cb + j;
             if (c < C) {
-                float *gp = grad_own + ((size_t)b * C + c) * plane + (size_t)y * W;
+                float *gp = grad_own + ((size_t)b * C + c) * plane + (size_t)y * W + xr;
+                if (al4 && xr + 3 < W) {
+                    *reinterpret_cast<float4 *>(gp) = make_float4(gacc[cb][0] * sc[0], gacc[cb][1] * sc[1],
+                                                                  gacc[cb][2] * sc[2], gacc[cb][3] * sc[3]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (xr + r < W) gp[xr + r] = gacc[cb][r] * sc[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (xr + r < W) gp[r] = gacc[cb][r] * sc[r];
+                }
             }
         }
         if (SIDE == 0 && VAR) {
             gdis += __shfl_xor(gdis, 16);
             gdis += __shfl_xor(gdis, 32);
-            if (inside && q == 0) {
-                const bool on = rmask[rowpix + x] != 0.f;
-                grad_disp[rowpix + x] = on ? -2.f * grad_out[rowpix + x] * gdis / sum_sim[rowpix + x] : 0.f;
-            }
+            // SV_kernel.cu:321-325: -2 g sum e (d - mu) / S; the own plane holds g / S (0 where the mask is off)
+            if (inside && q == 0) grad_disp[rowpix + x] = -2.f * OWNP[2 * SW + xt * 16 + j] * gdis;
         }
     }
 }
@@ -361,7 +407,7 @@ template <int NT, bool VAR, int SIDE>
 int side_xt(int cq, int W) {
     constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
     const int xt_row = ceil_div(W, 16);
-    auto bytes = [&](int xt) { return (size_t)4 * make_blayout(cq, NT, xt, NPL).total; };
+    auto bytes = [&](int xt) { return (size_t)4 * make_blayout(cq, NT, xt, NPL, bwd_nown(SIDE, VAR)).total; };
     const size_t budget2 = (DECNET_LDS_BYTES - 2048) / 2, budget1 = DECNET_LDS_BYTES - 1024;
     int XT = xt_row;
     if (bytes(XT) > budget2) {
@@ -382,7 +428,7 @@ int launch_side(const float *ref, const float *tar, const float *rmask, const fl
                 const float *grad_out, float *grad_own, float *grad_disp, int B, int C, int H, int W,
                 int D, int XT, int marker, hipStream_t stream) {
     constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
-    const size_t lds = (size_t)4 * make_blayout(4 * KQ, NT, XT, NPL).total;
+    const size_t lds = (size_t)4 * make_blayout(4 * KQ, NT, XT, NPL, bwd_nown(SIDE, VAR)).total;
     const int segs = ceil_div(ceil_div(W, 16), XT);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)spamat_bwd_mfma<NT, VAR, KQ, SIDE>,
