@@ -777,14 +777,20 @@ typedef int rb_i32x2 __attribute__((ext_vector_type(2)));
 #define RB_LDS __attribute__((address_space(3)))
 
 constexpr int RB_NW = 4;
-constexpr int RB_OFF_RIMG = 0;                            // ring of 16 right tiles x 16 pixels x 64 B
-constexpr int RB_OFF_LIMG = RB_OFF_RIMG + 16 * 1024;      // left tile, terms of L            [16 px][64 B]
-constexpr int RB_OFF_GIMG = RB_OFF_LIMG + 1024;           // left tile, terms of g/S L        [16 px][64 B]
-constexpr int RB_OFF_WT = RB_OFF_GIMG + 1024;             // per wave: 3 term planes [16 left][16 right] bf16 (512 B each)
-constexpr int RB_OFF_BZ = RB_OFF_WT + RB_NW * 1536;       // ring [16 tiles][16] floats: 0 / -1e30 of the right mask
-constexpr int RB_OFF_SC = RB_OFF_BZ + 1024;               // NM [16] | OUT [16] | GS [16] floats
-constexpr int RB_OFF_GLP = RB_OFF_SC + 256;               // [4 waves][64 lanes][4] partial left gradients
-constexpr int RB_LDS_BYTES = RB_OFF_GLP + RB_NW * 1024;
+// LDS layout of spamat_bwd_rowb<NT, CB> (bytes).  CB = channel blocks of 8 (C <= 8 CB); a pixel of an image is CB x 64 bytes.
+template <int NT, int CB>
+struct RbLayout {
+    static constexpr int RING = NT <= 8 ? 8 : 16;             // right tiles kept (a power of two >= NT)
+    static constexpr int PXB = 64 * CB, TILEB = 16 * PXB;
+    static constexpr int RIMG = 0;                            // ring of RING right tiles x 16 pixels x PXB
+    static constexpr int LIMG = RIMG + RING * TILEB;          // left tile, terms of L            [16 px][PXB]
+    static constexpr int GIMG = LIMG + TILEB;                 // left tile, terms of g/S L        [16 px][PXB]
+    static constexpr int WT = GIMG + TILEB;                   // per wave: 3 term planes [16 left][16 right] bf16 (512 B each)
+    static constexpr int BZ = WT + RB_NW * 1536;              // ring [RING][16] floats: 0 / -1e30 of the right mask
+    static constexpr int SC = BZ + RING * 64;                 // NM [16] | OUT [16] | GS [16] floats
+    static constexpr int GLP = SC + 256;                      // [4 waves][CB][64 lanes][4] partial left gradients
+    static constexpr int BYTES = GLP + RB_NW * CB * 1024;
+};
 
 __device__ __forceinline__ int rb_sw(int px) { return ((px >> 1) & 2) | ((px >> 3) & 1); }
 // weight-plane row of left pixel j: rows {0-3, 8-11} and {4-7, 12-15} (the two halves of a transposed read) on 8 distinct
@@ -807,15 +813,20 @@ __device__ __forceinline__ f32x4 rb_mfma(rb_i32x4 a, rb_i32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rb_bf16x8, a), __builtin_bit_cast(rb_bf16x8, b), c, 0, 0, 0);
 }
 
-template <int NT>
-__global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
+// CB > 1 (round 6: stage 2, C = 24): the same pass with CB channel blocks -- the cost tile sums CB x 2 MFMAs, each
+// contraction is 2 MFMAs per block on the block's own image columns, the weight tile (its exponentials, its split and its
+// trip through LDS) is formed ONCE for all blocks; replaces the two band launches there (each of which forms every weight
+// tile again, on fp32 MFMAs).
+template <int NT, int CB>
+__global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : 3) void spamat_bwd_rowb(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ out, const float *__restrict__ sum_sim,
     const float *__restrict__ max_cost, const float *__restrict__ grad_out, float *__restrict__ grad_ref,
     float *__restrict__ grad_tar, int C, int H, int W, int D, int marker) {
-    static_assert(NT <= 16, "band wider than the ring");
-    constexpr int NW = RB_NW, KS = (NT + NW - 1) / NW, NTHR = 64 * NW;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RB_LDS_BYTES];
+    using LO = RbLayout<NT, CB>;
+    static_assert(NT <= LO::RING, "band wider than the ring");
+    constexpr int NW = RB_NW, KS = (NT + NW - 1) / NW, NTHR = 64 * NW, RING = LO::RING, PXB = LO::PXB, TILEB = LO::TILEB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LO::BYTES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = blockIdx.x, b = row / H, y = row - b * H;
     const size_t plane = (size_t)H * W, rowpix = (size_t)row * W;
@@ -827,43 +838,51 @@ __global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
     const int qq = (lane & 15) >> 2, pp = lane & 3;      // address role in a transposed read: row qq of the group's four, piece pp
     const int XT = (W + 15) >> 4;
     const bool al4 = (W & 3) == 0 && ((((uintptr_t)grad_ref) | ((uintptr_t)grad_tar)) & 15) == 0;
-    float *BZ = reinterpret_cast<float *>(smem + RB_OFF_BZ);
-    float *NM = reinterpret_cast<float *>(smem + RB_OFF_SC), *OUT = NM + 16, *GS = NM + 32;
-    unsigned char *WT = smem + RB_OFF_WT + wave * 1536;
-    float *GLP = reinterpret_cast<float *>(smem + RB_OFF_GLP);
+    float *BZ = reinterpret_cast<float *>(smem + LO::BZ);
+    float *NM = reinterpret_cast<float *>(smem + LO::SC), *OUT = NM + 16, *GS = NM + 32;
+    unsigned char *WT = smem + LO::WT + wave * 1536;
+    float *GLP = reinterpret_cast<float *>(smem + LO::GLP);
 
-    for (int i = threadIdx.x; i < (RB_OFF_WT) / 16; i += NTHR)           // images: zero features, zero fourth chunks
+    for (int i = threadIdx.x; i < (LO::WT) / 16; i += NTHR)              // images: zero features, zero fourth chunks
         reinterpret_cast<float4 *>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = threadIdx.x; i < 16 * 16; i += NTHR) BZ[i] = NEG_BIG;
+    for (int i = threadIdx.x; i < RING * 16; i += NTHR) BZ[i] = NEG_BIG;
 
-    // per-lane byte offsets (constant over the row)
+    // per-lane byte offsets (constant over the row; channel block cb adds 64 cb)
     const int swj = rb_sw(j);
-    const int a1off = 64 * j + 16 * ((q >> 1) ^ swj);                    // cost A, MFMA 1: right terms  h h m m
-    const int a2off = 64 * j + 16 * (((q >> 1) * 2) ^ swj);              //         MFMA 2:              h h l l
+    const int a1off = PXB * j + 16 * ((q >> 1) ^ swj);                   // cost A, MFMA 1: right terms  h h m m
+    const int a2off = PXB * j + 16 * (((q >> 1) * 2) ^ swj);             //         MFMA 2:              h h l l
     const int pxr = 4 * q + qq;                                          // transposed read of the right image: pixel row
-    const int xoff = 64 * pxr + 16 * ((pp >> 1) ^ rb_sw(pxr)) + 8 * (pp & 1);          // columns (h | m)
-    // (columns (l | 0): chunk index ^ 2 = byte address ^ 32)
+    const int xoff = PXB * pxr + 16 * ((pp >> 1) ^ rb_sw(pxr)) + 8 * (pp & 1);         // columns (h | m)
+    // (columns (l | 0): chunk index ^ 2 = byte address ^ 32; every other summand of the address is a multiple of 64)
     const int wtw = rb_wt_addr(j, q);                                    // this lane's 8-byte piece of a weight plane
     const int lr0 = 8 * (q & 1) + qq, lr1 = lr0 + 4;                     // transposed reads over LEFT pixels: rows of the two reads
     const int p1 = q < 2 ? 0 : 512, p2 = q < 2 ? 0 : 1024;              // weight plane of this lane's K group: MFMA 1 h h m m, MFMA 2 h h l l
     const int u1a = p1 + rb_wt_addr(lr0, pp), u1b = p1 + rb_wt_addr(lr1, pp), ud2 = p2 - p1;
-    // staging roles: lane = (pixel j, channel pair q): channels 2q, 2q + 1 of one view; word q of a 16-byte chunk
-    const int imgw = 64 * j + 4 * q;
+    // staging roles: lane = (pixel j, channel pair q): channels 8 cb + 2q, + 1 of one view; word q of a 16-byte chunk
+    const int imgw = PXB * j + 4 * q;
 
     // values of the NEXT left tile, requested one tile ahead and not looked at before the next commit: every load is
     // unconditional (clamped pixel, channel and tile; what is outside is selected away at the commit) -- an exec-masked
     // load merged with a zero makes the compiler wait for memory right behind the request, i.e. one HBM round trip per
     // left tile in front of barrier (1) (the form of spamat_bwd_roww; found in the ISA, round 6).
     // wave 0: right view + right mask; wave 1: left view; wave 2: left view, g, S, left mask; wave 3: the per-pixel scalars
-    const int c0 = 2 * q < C ? 2 * q : 0, c1 = 2 * q + 1 < C ? 2 * q + 1 : 0;
-    const float *src0 = (wave == 0 ? rrow : lrow) + (size_t)c0 * plane, *src1 = (wave == 0 ? rrow : lrow) + (size_t)c1 * plane;
+    const float *srcv = wave == 0 ? rrow : lrow;
+    int co0[CB], co1[CB];                                                // element offsets of this lane's two channels per block
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        co0[cb] = (int)((8 * cb + 2 * q < C ? 8 * cb + 2 * q : 0) * plane);
+        co1[cb] = (int)((8 * cb + 2 * q + 1 < C ? 8 * cb + 2 * q + 1 : 0) * plane);
+    }
     const float *pm = (wave == 0 ? tmask : rmask) + rowpix;             // mask plane this wave looks at
     const float *pa = (wave == 2 ? grad_out : max_cost) + rowpix, *pb = (wave == 2 ? sum_sim : out) + rowpix;
-    float f0, f1, fm, fa, fb;
+    float f0[CB], f1[CB], fm, fa, fb;
     auto fetch = [&](int xt) {
         const int x = min(min(xt, XT - 1) * 16 + j, W - 1);
-        f0 = src0[x];
-        f1 = src1[x];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            f0[cb] = srcv[co0[cb] + x];
+            f1[cb] = srcv[co1[cb] + x];
+        }
         fm = pm[x];
         fa = pa[x];
         fb = pb[x];
@@ -878,18 +897,20 @@ __global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
     };
     fetch(0);
 
-    f32x4 gr[KS];                        // gr[k]: right tile xt - (m0 + 4k); lane (n = (term, channel), q), register r: pixel 4q + r
+    f32x4 gr[KS][CB];                    // gr[k]: right tile xt - (m0 + 4k); lane (n = (term, channel), q), register r: pixel 4q + r
 #pragma unroll
-    for (int k = 0; k < KS; ++k) gr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) gr[k][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // Finished gradient tiles are STORED one left tile later (behind the next barrier (1)): vmcnt counts stores too and
     // in order, so a store issued just in front of the next commit's wait for the prefetched values would put its own
     // round trip into every left tile's chain.
-    // One quad per lane is enough: a wave finishes a right tile where m0 + 4k = NT - 1, i.e. wave = xt - (NT - 1) (mod 4),
-    // and sums the left tile as wave = xt (mod 4): never both for one xt while (NT - 1) % 4 != 0.
+    // One quad per lane and block is enough: a wave finishes a right tile where m0 + 4k = NT - 1, i.e. wave = xt - (NT - 1)
+    // (mod 4), and sums the left tile as wave = xt (mod 4): never both for one xt while (NT - 1) % 4 != 0.
     static_assert((NT - 1) % RB_NW != 0, "a wave would finish a right tile and a left tile in one step");
-    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
-    int pq_x = -1;                                       // first pixel of this lane's pending quad (-1: none)
-    bool pq_right = false;                               // (wave-uniform) which gradient it belongs to
+    float4 pq[CB];
+    int pq_x = -1;                                       // first pixel of this lane's pending quads (-1: none)
+    bool pq_right = false;                               // (wave-uniform) which gradient they belong to
     auto store4 = [&](float *gp, int x, const float4 &o) {
         if (al4 && x + 3 < W) {
             *reinterpret_cast<float4 *>(gp) = o;
@@ -901,72 +922,92 @@ __global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
         }
     };
     auto flush_pending = [&]() {
-        if (pq_x >= 0) store4((pq_right ? grrow : glrow) + (size_t)j * plane + pq_x, pq_x, pq);
+        if (pq_x >= 0) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                if (8 * cb + j < C) store4((pq_right ? grrow : glrow) + (size_t)(8 * cb + j) * plane + pq_x, pq_x, pq[cb]);
+        }
         pq_x = -1;
     };
-    auto finish_right = [&](int t, const f32x4 &gpart) { // right tile t complete -> pending grad_tar quad (0 where the right mask is off)
+    auto finish_right = [&](int t, const f32x4 (&gpart)[CB]) { // right tile t complete -> pending grad_tar quads (0 where the right mask is off)
         if (t < 0) return;                               // (wave-uniform)
         pq_right = true;
-        f32x4 gsum;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gsum[r] = gpart[r] + __shfl_xor(gpart[r], 8);     // + the other term half of N
         const int x = t * 16 + 4 * q;
-        if (j >= 8 || j >= C || x >= W) return;
-        const float4 bz = *reinterpret_cast<const float4 *>(BZ + (t & 15) * 16 + 4 * q);
-        pq = make_float4(bz.x == 0.f ? gsum[0] : 0.f, bz.y == 0.f ? gsum[1] : 0.f, bz.z == 0.f ? gsum[2] : 0.f,
-                         bz.w == 0.f ? gsum[3] : 0.f);
-        pq_x = x;
+        const float4 bz = *reinterpret_cast<const float4 *>(BZ + (t & (RING - 1)) * 16 + 4 * q);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            f32x4 gsum;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gsum[r] = gpart[cb][r] + __shfl_xor(gpart[cb][r], 8);     // + the other term half of N
+            pq[cb] = make_float4(bz.x == 0.f ? gsum[0] : 0.f, bz.y == 0.f ? gsum[1] : 0.f, bz.z == 0.f ? gsum[2] : 0.f,
+                                 bz.w == 0.f ? gsum[3] : 0.f);
+        }
+        if (j < 8 && x < W) pq_x = x;
     };
     __syncthreads();                                     // the zeroed images
 
     for (int xt = 0; xt < XT; ++xt) {
-        const int x0 = xt * 16, s0 = xt & 15;
+        const int x0 = xt * 16, s0 = xt & (RING - 1);
         const int m0 = (xt - wave) & (NW - 1);           // this wave's band tiles: m0, m0 + NW, ...
         if (xt > 0 && m0 == 0) {                         // the window slides: a new right tile (t = xt) enters at k = 0
 #pragma unroll
-            for (int k = KS - 1; k > 0; --k) gr[k] = gr[k - 1];
-            gr[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+                for (int k = KS - 1; k > 0; --k) gr[k][cb] = gr[k - 1][cb];
+                gr[0][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
-        // commit tile xt (ring slot s0 held right tile xt - 16: dead since left tile xt - 2)
+        // commit tile xt (ring slot s0 held right tile xt - RING: dead since left tile xt - 2)
         {
             const bool okx = x0 + j < W;
-            const float v0 = (okx && 2 * q < C) ? f0 : 0.f, v1 = (okx && 2 * q + 1 < C) ? f1 : 0.f;
             const bool on = okx && fm != 0.f;
-            if (wave == 0) {
-                put_image(smem + RB_OFF_RIMG + s0 * 1024, v0, v1);
-                if (q == 0) BZ[s0 * 16 + j] = on ? 0.f : NEG_BIG;
-            } else if (wave == 1) {
-                put_image(smem + RB_OFF_LIMG, v0, v1);
-            } else if (wave == 2) {
-                const float gsv = on ? fa / fb : 0.f;                  // g / S, 0 where the left mask is off
-                put_image(smem + RB_OFF_GIMG, v0 * gsv, v1 * gsv);     // SM_kernel.cu:346: g/S L[c][left]
-                if (q == 0) GS[j] = gsv;
-            } else if (q == 0) {
-                NM[j] = on ? -fa * LOG2E : NEG_BIG;                    // masked-off / out-of-row left pixel: weights 0
-                OUT[j] = fb;
+            const float gsv = (wave == 2 && on) ? fa / fb : 0.f;         // g / S, 0 where the left mask is off
+            unsigned char *img = smem + (wave == 0 ? LO::RIMG + s0 * TILEB : wave == 1 ? LO::LIMG : LO::GIMG);
+            if (wave < 3) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    float v0 = (okx && 8 * cb + 2 * q < C) ? f0[cb] : 0.f, v1 = (okx && 8 * cb + 2 * q + 1 < C) ? f1[cb] : 0.f;
+                    if (wave == 2) { v0 *= gsv; v1 *= gsv; }             // SM_kernel.cu:346: g/S L[c][left]
+                    put_image(img + 64 * cb, v0, v1);
+                }
+            }
+            if (q == 0) {
+                if (wave == 0) BZ[s0 * 16 + j] = on ? 0.f : NEG_BIG;
+                if (wave == 2) GS[j] = gsv;
+                if (wave == 3) {
+                    NM[j] = on ? -fa * LOG2E : NEG_BIG;                  // masked-off / out-of-row left pixel: weights 0
+                    OUT[j] = fb;
+                }
             }
         }
         fetch(xt + 1);
         __syncthreads();                                 // (1) tile xt is in the ring, the left tile's images and scalars are up
         flush_pending();                                 // the gradient quads finished during the previous left tile
         // cost B operands: left terms h m h m | l 0 h m of the K groups
-        const rb_i32x4 bl1 = *reinterpret_cast<const rb_i32x4 *>(smem + RB_OFF_LIMG + 64 * j + 16 * ((q & 1) ^ swj));
-        const rb_i32x4 bl2 = *reinterpret_cast<const rb_i32x4 *>(smem + RB_OFF_LIMG + 64 * j + 16 * ((q ^ 2) ^ swj));
-        rb_i32x4 G1, G2;
+        rb_i32x4 bl1[CB], bl2[CB], G1[CB], G2[CB];
         {
             // g/S L image: MFMA 1 columns (h | m) for every K group; MFMA 2: (l | 0) beside w_h, (h | m) beside w_l
             const int gch2 = q < 2 ? 2 + (pp >> 1) : (pp >> 1);
-            const int g1a = RB_OFF_GIMG + 64 * lr0 + 16 * ((pp >> 1) ^ rb_sw(lr0)) + 8 * (pp & 1);
-            const int g1b = RB_OFF_GIMG + 64 * lr1 + 16 * ((pp >> 1) ^ rb_sw(lr1)) + 8 * (pp & 1);
-            const int g2a = RB_OFF_GIMG + 64 * lr0 + 16 * (gch2 ^ rb_sw(lr0)) + 8 * (pp & 1);
-            const int g2b = RB_OFF_GIMG + 64 * lr1 + 16 * (gch2 ^ rb_sw(lr1)) + 8 * (pp & 1);
-            const rb_i32x2 a = rb_tr16(smem + g1a), bq = rb_tr16(smem + g1b), c2 = rb_tr16(smem + g2a), d2 = rb_tr16(smem + g2b);
-            G1 = rb_i32x4{a[0], a[1], bq[0], bq[1]};
-            G2 = rb_i32x4{c2[0], c2[1], d2[0], d2[1]};
+            const int g1a = LO::GIMG + PXB * lr0 + 16 * ((pp >> 1) ^ rb_sw(lr0)) + 8 * (pp & 1);
+            const int g1b = LO::GIMG + PXB * lr1 + 16 * ((pp >> 1) ^ rb_sw(lr1)) + 8 * (pp & 1);
+            const int g2a = LO::GIMG + PXB * lr0 + 16 * (gch2 ^ rb_sw(lr0)) + 8 * (pp & 1);
+            const int g2b = LO::GIMG + PXB * lr1 + 16 * (gch2 ^ rb_sw(lr1)) + 8 * (pp & 1);
+            const int l1o = LO::LIMG + PXB * j + 16 * ((q & 1) ^ swj), l2o = LO::LIMG + PXB * j + 16 * ((q ^ 2) ^ swj);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                bl1[cb] = *reinterpret_cast<const rb_i32x4 *>(smem + l1o + 64 * cb);
+                bl2[cb] = *reinterpret_cast<const rb_i32x4 *>(smem + l2o + 64 * cb);
+                const rb_i32x2 a = rb_tr16(smem + g1a + 64 * cb), bq = rb_tr16(smem + g1b + 64 * cb),
+                               c2 = rb_tr16(smem + g2a + 64 * cb), d2 = rb_tr16(smem + g2b + 64 * cb);
+                G1[cb] = rb_i32x4{a[0], a[1], bq[0], bq[1]};
+                G2[cb] = rb_i32x4{c2[0], c2[1], d2[0], d2[1]};
+            }
         }
         const float nm_own = NM[j], out_own = OUT[j];
         const float dm0 = (float)(j - 4 * q) - out_own;                              // d - out = 16 m - r + dm0
-        f32x4 gl = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 gl[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) gl[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int m = m0 + NW * k;
@@ -974,10 +1015,8 @@ __global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
             // branching around them saves the 16 v_mov per tile the branch costs (the compiler copies the window of
             // right-gradient accumulators at every merge) but adds one tile in sixteen: measured 0.436 -> 0.46 ms, not kept.
             if (m >= NT || m > xt) continue;
-            const int ob = ((xt - m) & 15) * 1024;
-            const rb_i32x4 a1 = *reinterpret_cast<const rb_i32x4 *>(smem + RB_OFF_RIMG + ob + a1off);
-            const rb_i32x4 a2 = *reinterpret_cast<const rb_i32x4 *>(smem + RB_OFF_RIMG + ob + a2off);
-            const float4 bz = *reinterpret_cast<const float4 *>(smem + RB_OFF_BZ + (ob >> 4) + 16 * q);
+            const int ob = ((xt - m) & (RING - 1)) * TILEB;
+            const float4 bz = *reinterpret_cast<const float4 *>(BZ + ((xt - m) & (RING - 1)) * 16 + 4 * q);
             f32x4 cst = f32x4{bz.x, bz.y, bz.z, bz.w};
             if (m == 0 || 16 * m + 15 >= D) {            // (wave-uniform) edge tiles of the band: 0 <= d < D
 #pragma unroll
@@ -986,9 +1025,13 @@ __global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
                     cst[r] = (unsigned)d < (unsigned)D ? cst[r] : NEG_BIG;
                 }
             }
-            cst = rb_mfma(a1, bl1, cst);
-            cst = rb_mfma(a2, bl2, cst);
-            const rb_i32x2 X = rb_tr16(smem + RB_OFF_RIMG + ob + xoff), Y = rb_tr16(smem + RB_OFF_RIMG + ((ob + xoff) ^ 32));
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const rb_i32x4 a1 = *reinterpret_cast<const rb_i32x4 *>(smem + LO::RIMG + ob + a1off + 64 * cb);
+                const rb_i32x4 a2 = *reinterpret_cast<const rb_i32x4 *>(smem + LO::RIMG + ob + a2off + 64 * cb);
+                cst = rb_mfma(a1, bl1[cb], cst);
+                cst = rb_mfma(a2, bl2[cb], cst);
+            }
             const float dm = dm0 + (float)(16 * m);
             int wh[4], wm[4], wl[4];
 #pragma unroll
@@ -1010,41 +1053,52 @@ __global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // left gradient: A = own weight terms (K = right pixels 4q + r x 2 slots), B = right image columns
-            gl = rb_mfma(rb_i32x4{h01, h23, m01, m23}, rb_i32x4{X[0], X[1], X[0], X[1]}, gl);   // (w_h + w_m)(R_h | R_m)
-            gl = rb_mfma(rb_i32x4{h01, h23, l01, l23}, rb_i32x4{Y[0], Y[1], X[0], X[1]}, gl);   // w_h (R_l | 0) + w_l (R_h | R_m)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const rb_i32x2 X = rb_tr16(smem + LO::RIMG + ob + xoff + 64 * cb),
+                               Y = rb_tr16(smem + LO::RIMG + ((ob + xoff + 64 * cb) ^ 32));
+                gl[cb] = rb_mfma(rb_i32x4{h01, h23, m01, m23}, rb_i32x4{X[0], X[1], X[0], X[1]}, gl[cb]);   // (w_h + w_m)(R_h | R_m)
+                gl[cb] = rb_mfma(rb_i32x4{h01, h23, l01, l23}, rb_i32x4{Y[0], Y[1], X[0], X[1]}, gl[cb]);   // w_h (R_l | 0) + w_l (R_h | R_m)
+            }
             // right gradient: A = the planes read back transposed (K = left pixels x 2 slots), B = g/S L image columns
             {
                 const rb_i32x2 ua = rb_tr16(WT + u1a), ub = rb_tr16(WT + u1b), uc = rb_tr16(WT + u1a + ud2),
                                ud = rb_tr16(WT + u1b + ud2);
-                gr[k] = rb_mfma(rb_i32x4{ua[0], ua[1], ub[0], ub[1]}, G1, gr[k]);
-                gr[k] = rb_mfma(rb_i32x4{uc[0], uc[1], ud[0], ud[1]}, G2, gr[k]);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    gr[k][cb] = rb_mfma(rb_i32x4{ua[0], ua[1], ub[0], ub[1]}, G1[cb], gr[k][cb]);
+                    gr[k][cb] = rb_mfma(rb_i32x4{uc[0], uc[1], ud[0], ud[1]}, G2[cb], gr[k][cb]);
+                }
             }
             if (m == NT - 1) {                           // right tile xt - m has seen all its left tiles
                 finish_right(xt - m, gr[k]);
-                gr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) gr[k][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         // this wave's share of the left tile's gradient -> LDS; summed in a fixed order by wave xt mod 4
-        *reinterpret_cast<float4 *>(GLP + wave * 256 + lane * 4) = make_float4(gl[0], gl[1], gl[2], gl[3]);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+            *reinterpret_cast<float4 *>(GLP + (wave * CB + cb) * 256 + lane * 4) = make_float4(gl[cb][0], gl[cb][1], gl[cb][2], gl[cb][3]);
         const bool summer = wave == (xt & (NW - 1)) && j < 8;
         float4 gs4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (summer) gs4 = *reinterpret_cast<const float4 *>(GS + 4 * q);
         __syncthreads();                                 // (2) partials complete; the left tile's images may be overwritten
         if (wave == (xt & (NW - 1))) pq_right = false;
         if (summer) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) {            // both term halves of N (lanes n, n + 8) of every wave
-                const float4 pa = *reinterpret_cast<const float4 *>(GLP + w2 * 256 + lane * 4);
-                const float4 pb = *reinterpret_cast<const float4 *>(GLP + w2 * 256 + (lane + 8) * 4);
-                acc.x += pa.x + pb.x; acc.y += pa.y + pb.y; acc.z += pa.z + pb.z; acc.w += pa.w + pb.w;
+            for (int cb = 0; cb < CB; ++cb) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) {        // both term halves of N (lanes n, n + 8) of every wave
+                    const float4 pa4 = *reinterpret_cast<const float4 *>(GLP + (w2 * CB + cb) * 256 + lane * 4);
+                    const float4 pb4 = *reinterpret_cast<const float4 *>(GLP + (w2 * CB + cb) * 256 + (lane + 8) * 4);
+                    acc.x += pa4.x + pb4.x; acc.y += pa4.y + pb4.y; acc.z += pa4.z + pb4.z; acc.w += pa4.w + pb4.w;
+                }
+                // lane (n = channel, q): left pixels x0 + 4q + r: grad_ref = g * sum / S (SM_kernel.cu:193)
+                pq[cb] = make_float4(acc.x * gs4.x, acc.y * gs4.y, acc.z * gs4.z, acc.w * gs4.w);
             }
-            // lane (n = channel, q): left pixels x0 + 4q + r: grad_ref = g * sum / S (SM_kernel.cu:193)
-            const int x = x0 + 4 * q;
-            if (j < C && x < W) {
-                pq = make_float4(acc.x * gs4.x, acc.y * gs4.y, acc.z * gs4.z, acc.w * gs4.w);
-                pq_x = x;
-            }
+            if (x0 + 4 * q < W) pq_x = x0 + 4 * q;
         }
     }
     flush_pending();
@@ -1062,11 +1116,12 @@ __global__ __launch_bounds__(64 * RB_NW, 4) void spamat_bwd_rowb(
     }
 }
 
-template <int NT>
+template <int NT, int CB>
 int launch_row(const float *ref, const float *tar, const float *rmask, const float *tmask, const float *out,
                const float *sum_sim, const float *max_cost, const float *grad_out, float *grad_ref, float *grad_tar,
                int B, int C, int H, int W, int D, int marker, hipStream_t stream) {
-    hipLaunchKernelGGL((spamat_bwd_rowb<NT>), dim3((unsigned)((size_t)B * H)), dim3(64 * RB_NW), 0, stream, ref, tar, rmask,
+    if ((double)C * H * W >= 2147483648.0) return DECNET_ERR_UNSUPPORTED;        // 32-bit element offsets inside a sample
+    hipLaunchKernelGGL((spamat_bwd_rowb<NT, CB>), dim3((unsigned)((size_t)B * H)), dim3(64 * RB_NW), 0, stream, ref, tar, rmask,
                        tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, C, H, W, D, marker);
     return decnet_launch_status();
 }
@@ -1126,8 +1181,18 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
     // the path of SpaVar, of C > 8 and of rows narrower than the band)
     if constexpr (KQ == 2 && !VAR && NT <= 15) {
         if (W >= 16 * NT)
-            return launch_row<NT>(ref, tar, rmask, tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, B, C, H, W,
-                                  D, marker, stream);
+            return launch_row<NT, 1>(ref, tar, rmask, tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, B, C, H, W,
+                                     D, marker, stream);
+    }
+    // ... and at 9 - 24 channels (stage 2) with two / three channel blocks (round 6)
+    if constexpr (KQ == 6 && !VAR && NT <= 11) {
+        if (W >= 16 * NT) {
+            int rc = C <= 16 ? launch_row<NT, 2>(ref, tar, rmask, tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, B, C,
+                                                H, W, D, marker, stream)
+                             : launch_row<NT, 3>(ref, tar, rmask, tmask, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, B, C,
+                                                H, W, D, marker, stream);
+            if (rc != DECNET_ERR_UNSUPPORTED) return rc;
+        }
     }
     int rc = launch_side<NT, VAR, KQ, 0>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
                                          grad_out, grad_ref, grad_disp, B, C, H, W, D, xt0, marker, stream);
