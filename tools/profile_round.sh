@@ -38,8 +38,8 @@ cd /tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bf -o f -- python3 $R/tools/bench_spamat_bwd.py --stage 3 --batch 4 --iters 5 > /dev/null 2> $O/pmc_bf.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bw -o w -- python3 $R/tools/bench_spamat_bwd.py --stage 3 --batch 4 --iters 5 > /dev/null 2> $O/pmc_bw.err
 cd $R
-# (round 4: dense rows at C <= 8 are ONE launch, spamat_bwd_roww; the band kernels only where that one does not apply)
-python3 tools/pmc_kernels.py $O/pmc_bf $O/pmc_bw $O/${TAG}_pmc_extra_raw.json $O/traffic.json "spamat_bwd_stage3=spamat_bwd_roww<15+spamat_bwd_mfma<15"
+# (dense rows at C <= 8 are ONE launch, spamat_bwd_rowb; the band kernels only where that one does not apply)
+python3 tools/pmc_kernels.py $O/pmc_bf $O/pmc_bw $O/${TAG}_pmc_extra_raw.json $O/traffic.json "spamat_bwd_stage3=spamat_bwd_rowb<15+spamat_bwd_mfma<15"
 rm -rf $O/pmc_* $O/trace
 # one whole-graph forward, per kernel (tools/e2e_profile.py under a kernel trace)
 cd /tmp
