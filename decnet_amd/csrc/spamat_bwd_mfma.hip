@@ -818,7 +818,7 @@ __device__ __forceinline__ f32x4 rb_mfma(rb_i32x4 a, rb_i32x4 b, f32x4 c) {
 // trip through LDS) is formed ONCE for all blocks; replaces the two band launches there (each of which forms every weight
 // tile again, on fp32 MFMAs).
 template <int NT, int CB>
-__global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : 3) void spamat_bwd_rowb(
+__global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : (CB == 3 && NT > 8) ? 2 : 3) void spamat_bwd_rowb(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ out, const float *__restrict__ sum_sim,
     const float *__restrict__ max_cost, const float *__restrict__ grad_out, float *__restrict__ grad_ref,
@@ -860,6 +860,13 @@ __global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : 3) void spamat_bwd_rowb(
     const int u1a = p1 + rb_wt_addr(lr0, pp), u1b = p1 + rb_wt_addr(lr1, pp), ud2 = p2 - p1;
     // staging roles: lane = (pixel j, channel pair q): channels 8 cb + 2q, + 1 of one view; word q of a 16-byte chunk
     const int imgw = PXB * j + 4 * q;
+    // per-left-tile operand reads (lane constants held in registers: recomputing them cost ~25 vector instructions per left
+    // tile and wave).  g/S L image, MFMA 1: columns (h | m) for every K group; MFMA 2: (l | 0) beside w_h (K groups 0, 1),
+    // (h | m) beside w_l -- chunk index ^ 2 = byte address ^ 32.  Cost B operands: left terms h m h m | l 0 h m.
+    const int g1a = LO::GIMG + PXB * lr0 + 16 * ((pp >> 1) ^ rb_sw(lr0)) + 8 * (pp & 1);
+    const int g1b = LO::GIMG + PXB * lr1 + 16 * ((pp >> 1) ^ rb_sw(lr1)) + 8 * (pp & 1);
+    const int l1o = LO::LIMG + PXB * j + 16 * ((q & 1) ^ swj);
+    const int x32 = q < 2 ? 32 : 0;
 
     // values of the NEXT left tile, requested one tile ahead and not looked at before the next commit: every load is
     // unconditional (clamped pixel, channel and tile; what is outside is selected away at the commit) -- an exec-masked
@@ -986,13 +993,7 @@ __global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : 3) void spamat_bwd_rowb(
         // cost B operands: left terms h m h m | l 0 h m of the K groups
         rb_i32x4 bl1[CB], bl2[CB], G1[CB], G2[CB];
         {
-            // g/S L image: MFMA 1 columns (h | m) for every K group; MFMA 2: (l | 0) beside w_h, (h | m) beside w_l
-            const int gch2 = q < 2 ? 2 + (pp >> 1) : (pp >> 1);
-            const int g1a = LO::GIMG + PXB * lr0 + 16 * ((pp >> 1) ^ rb_sw(lr0)) + 8 * (pp & 1);
-            const int g1b = LO::GIMG + PXB * lr1 + 16 * ((pp >> 1) ^ rb_sw(lr1)) + 8 * (pp & 1);
-            const int g2a = LO::GIMG + PXB * lr0 + 16 * (gch2 ^ rb_sw(lr0)) + 8 * (pp & 1);
-            const int g2b = LO::GIMG + PXB * lr1 + 16 * (gch2 ^ rb_sw(lr1)) + 8 * (pp & 1);
-            const int l1o = LO::LIMG + PXB * j + 16 * ((q & 1) ^ swj), l2o = LO::LIMG + PXB * j + 16 * ((q ^ 2) ^ swj);
+            const int g2a = g1a ^ x32, g2b = g1b ^ x32, l2o = l1o ^ x32;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 bl1[cb] = *reinterpret_cast<const rb_i32x4 *>(smem + l1o + 64 * cb);

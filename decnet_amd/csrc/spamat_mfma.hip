@@ -426,9 +426,9 @@ __device__ __forceinline__ void softmax_passes(f32x4 (&acc)[NTL], int ntile, int
 // ~5 % of the softmax work instead of ~20 %.  LDS: 48 bytes per staged position and channel group for each
 // side, so a 972-pixel row of stage 3 is two segments (63 KB each, two workgroups per CU).
 // BX (right-mask bias) and LM (left mask) are filled by the caller's phase 1.
-// 8 channel rows x 4 positions of one view.  Positions outside the row are NOT zeroed on the aligned path (they read the
-// row's first group): a right pixel outside the row has the -1e30 bias (BX: its mask reads as 0), a left pixel outside it
-// is never stored.  Channels that do not exist are zeros.
+// 8 channel rows x 4 positions of one view.  Positions right of the row are NOT zeroed on the aligned path (they read the
+// row's first group): a right pixel there has the -1e30 bias (BX: its mask reads as 0) and only negative disparities, a left
+// pixel outside the row is never stored.  Positions left of the row and channels that do not exist are zeros.
 __device__ __forceinline__ void dense16_loads8(float4 (&v)[8], const float *__restrict__ src, size_t plane, int g, int C,
                                                int x, int W, bool al) {
     if (al) {
@@ -437,6 +437,16 @@ __device__ __forceinline__ void dense16_loads8(float4 (&v)[8], const float *__re
         for (int c = 0; c < 8; ++c)
             v[c] = load4f<false>(src, src + (size_t)(8 * g + c) * plane, x, W, whole && 8 * g + c < C);
         __builtin_amdgcn_sched_barrier(0);              // all eight requests before anything that waits for one
+        // positions LEFT of the row (the first segment's halo) read the row's first group: finite-but-ignored under the
+        // -1e30 bias as long as that group is finite -- a NaN / Inf there would reach candidates (x' < 0, d <= D - 1) of left
+        // pixels whose candidate set does not hold it, against the header's contract: zeros instead (one wave-uniform
+        // branch; only the waves that stage such positions take it).  Positions right of the row need nothing: every tile
+        // row there has d < 0 and the range select replaces it.
+        if (__ballot(x < 0) != 0ull) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (x < 0) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (C & 7) {                                    // (uniform) a partial channel group: its missing channels are zeros
 #pragma unroll
             for (int c = 0; c < 8; ++c) {

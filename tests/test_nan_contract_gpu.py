@@ -90,3 +90,20 @@ def test_without_the_knob_a_nan_never_faults_or_spreads():
     keep[0, 2, 200:264] = False
     for a, b in ((o0, o1), (v0, v1), (s0, s1), (m0, m1)):
         assert torch.equal(a[keep], b[keep])
+    # the row's FIRST group is what staging lanes left of the row read on the aligned path (then zeroed): a NaN in right
+    # pixel 3 of channel 0 belongs to left pixels 3 .. 66 only -- pixels 0 .. 2 keep their values (round 5 advice); the same
+    # for the row's first and last elements of either view, dense rows (max_disp 216) and the fp32 band path (64)
+    for D in (64, 216):
+        o0, v0, s0, m0 = decnet_amd.spamatvar_forward(L, R, m, m, D)
+        for side, x in ((1, 3), (1, 0), (0, 0), (0, 399), (1, 399)):
+            L2, R2 = L.clone(), R.clone()
+            (L2 if side == 0 else R2)[0, 0, 1, x] = float("nan")
+            o1, v1, s1, m1 = decnet_amd.spamatvar_forward(L2, R2, m, m, D)
+            torch.cuda.synchronize()
+            keep = torch.ones(1, 4, 400, dtype=torch.bool, device=dev)
+            if side == 0:
+                keep[0, 1, x] = False                       # a left feature belongs to its own pixel only
+            else:
+                keep[0, 1, x:min(400, x + D)] = False       # right pixel x is a candidate of left pixels x .. x + D - 1
+            for a, b in ((o0, o1), (v0, v1), (s0, s1), (m0, m1)):
+                assert torch.equal(a[keep], b[keep]), (D, side, x)
