@@ -874,11 +874,11 @@ __global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : (CB == 3 && NT > 8) ? 2 :
     // left tile in front of barrier (1) (the form of spamat_bwd_roww; found in the ISA, round 6).
     // wave 0: right view + right mask; wave 1: left view; wave 2: left view, g, S, left mask; wave 3: the per-pixel scalars
     const float *srcv = wave == 0 ? rrow : lrow;
-    int co0[CB], co1[CB];                                                // element offsets of this lane's two channels per block
+    const float *src0[CB], *src1[CB];                                    // this lane's two channel rows per block
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
-        co0[cb] = (int)((8 * cb + 2 * q < C ? 8 * cb + 2 * q : 0) * plane);
-        co1[cb] = (int)((8 * cb + 2 * q + 1 < C ? 8 * cb + 2 * q + 1 : 0) * plane);
+        src0[cb] = srcv + (size_t)(8 * cb + 2 * q < C ? 8 * cb + 2 * q : 0) * plane;
+        src1[cb] = srcv + (size_t)(8 * cb + 2 * q + 1 < C ? 8 * cb + 2 * q + 1 : 0) * plane;
     }
     const float *pm = (wave == 0 ? tmask : rmask) + rowpix;             // mask plane this wave looks at
     const float *pa = (wave == 2 ? grad_out : max_cost) + rowpix, *pb = (wave == 2 ? sum_sim : out) + rowpix;
@@ -887,8 +887,8 @@ __global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : (CB == 3 && NT > 8) ? 2 :
         const int x = min(min(xt, XT - 1) * 16 + j, W - 1);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            f0[cb] = srcv[co0[cb] + x];
-            f1[cb] = srcv[co1[cb] + x];
+            f0[cb] = src0[cb][x];
+            f1[cb] = src1[cb][x];
         }
         fm = pm[x];
         fa = pa[x];
@@ -964,27 +964,33 @@ __global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : (CB == 3 && NT > 8) ? 2 :
                 gr[0][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        // commit tile xt (ring slot s0 held right tile xt - RING: dead since left tile xt - 2)
+        // commit tile xt (ring slot s0 held right tile xt - RING: dead since left tile xt - 2).  One branch per wave role
+        // (a shared body with `wave == 2 ? ... : ...` inside was if-converted: all four waves ran the division)
         {
             const bool okx = x0 + j < W;
             const bool on = okx && fm != 0.f;
-            const float gsv = (wave == 2 && on) ? fa / fb : 0.f;         // g / S, 0 where the left mask is off
-            unsigned char *img = smem + (wave == 0 ? LO::RIMG + s0 * TILEB : wave == 1 ? LO::LIMG : LO::GIMG);
-            if (wave < 3) {
+            float v0[CB], v1[CB];
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    float v0 = (okx && 8 * cb + 2 * q < C) ? f0[cb] : 0.f, v1 = (okx && 8 * cb + 2 * q + 1 < C) ? f1[cb] : 0.f;
-                    if (wave == 2) { v0 *= gsv; v1 *= gsv; }             // SM_kernel.cu:346: g/S L[c][left]
-                    put_image(img + 64 * cb, v0, v1);
-                }
+            for (int cb = 0; cb < CB; ++cb) {
+                v0[cb] = (okx && 8 * cb + 2 * q < C) ? f0[cb] : 0.f;
+                v1[cb] = (okx && 8 * cb + 2 * q + 1 < C) ? f1[cb] : 0.f;
             }
-            if (q == 0) {
-                if (wave == 0) BZ[s0 * 16 + j] = on ? 0.f : NEG_BIG;
-                if (wave == 2) GS[j] = gsv;
-                if (wave == 3) {
-                    NM[j] = on ? -fa * LOG2E : NEG_BIG;                  // masked-off / out-of-row left pixel: weights 0
-                    OUT[j] = fb;
-                }
+            if (wave == 0) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) put_image(smem + LO::RIMG + s0 * TILEB + 64 * cb, v0[cb], v1[cb]);
+                if (q == 0) BZ[s0 * 16 + j] = on ? 0.f : NEG_BIG;
+            } else if (wave == 1) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) put_image(smem + LO::LIMG + 64 * cb, v0[cb], v1[cb]);
+            } else if (wave == 2) {
+                const float gsv = on ? fa / fb : 0.f;                  // g / S, 0 where the left mask is off
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)                        // SM_kernel.cu:346: g/S L[c][left]
+                    put_image(smem + LO::GIMG + 64 * cb, v0[cb] * gsv, v1[cb] * gsv);
+                if (q == 0) GS[j] = gsv;
+            } else if (q == 0) {
+                NM[j] = on ? -fa * LOG2E : NEG_BIG;                    // masked-off / out-of-row left pixel: weights 0
+                OUT[j] = fb;
             }
         }
         fetch(xt + 1);
