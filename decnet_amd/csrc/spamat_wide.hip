@@ -8,7 +8,9 @@
 // is a masked-off pixel of the shifted view.  Bands are merged per pixel like chunks of an online softmax:
 //     m = max(m_a, m_b),   S - 1e-6 = (S_a - 1e-6) e^(m_a - m) + (S_b - 1e-6) e^(m_b - m),
 //     T = sum e d:  T_b = out_b S_b - 1e-6 + d0 (S_b - 1e-6),   out = (1e-6 + T) / S          (SM_kernel.cu:110-122)
-// and the variance the same way with the band's disparity input shifted by d0 (SV_kernel.cu:112-121).  A band without a
+// and the variance the same way with the band's disparity input shifted by d0 (SV_kernel.cu:112-121); the FUSED call
+// (variance around its own disparity) is one sweep of fused band calls merged by the parallel-variance rule
+// (merge_band_fused).  A band without a
 // valid candidate comes back as m_b = 1e-6, S_b = 1e-6, out_b = 1 and contributes exactly nothing.  The backward kernels
 // take the GLOBAL max / sum / output (minus d0 where it is a disparity), write the band's gradients into scratch planes and
 // those are accumulated (the right gradient shifted back by d0).  Scratch comes from the stream-ordered allocator
@@ -58,6 +60,35 @@ __global__ __launch_bounds__(EW_THREADS) void merge_band(const float *__restrict
         const float Qa = q[i] * S[i] - 1e-6f, Qb = qb[i] * Sb[i] - 1e-6f + d0f * Eb;
         const float Sn = 1e-6f + (Ea * ea + Eb * eb);
         q[i] = (1e-6f + (Qa * ea + Qb * eb)) / Sn;
+        S[i] = Sn;
+        m[i] = mn;
+    }
+}
+// The fused call in ONE sweep: every band returns its own disparity q_b AND the variance v_b around it; two parts A, B with
+// sums of exponentials E, first moments T and second moments V around their own means o combine around the joint mean mu as
+//     V(mu) = sum_X e^(m_X - m) (V_X + 2 (o_X - mu) c_X + (o_X - mu)^2 E_X),   c_X = T_X - o_X E_X = 1e-6 (o_X - 1)
+// (c_X from the definitions out = (1e-6 + T) / (1e-6 + E): exact, no difference of two rounded products).  Every term
+// but the tiny c_X one is non-negative: no cancellation.  Running (q, v, S, m) <- merge with band (q_b, v_b, S_b, m_b) at d0.
+__global__ __launch_bounds__(EW_THREADS) void merge_band_fused(const float *__restrict__ rmask, float *__restrict__ q,
+                                                               float *__restrict__ v, float *__restrict__ S,
+                                                               float *__restrict__ m, const float *__restrict__ qb,
+                                                               const float *__restrict__ vb, const float *__restrict__ Sb,
+                                                               const float *__restrict__ mb, size_t n, float d0f) {
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * EW_THREADS) {
+        if (rmask[i] == 0.f) continue;
+        const float ma = m[i], mbv = mb[i], mn = fmaxf(ma, mbv);
+        const float ea = expf(ma - mn), eb = expf(mbv - mn);
+        const float Sa = S[i], Sbv = Sb[i], Ea = Sa - 1e-6f, Eb = Sbv - 1e-6f;
+        const float oa = q[i], ob = qb[i] + d0f;                             // the parts' own means, global coordinates
+        const float Ta = oa * Sa - 1e-6f, Tb = qb[i] * Sbv - 1e-6f + d0f * Eb;
+        const float Va = v[i] * Sa - 1e-6f, Vb = vb[i] * Sbv - 1e-6f;
+        const float Sn = 1e-6f + (Ea * ea + Eb * eb);
+        const float mu = (1e-6f + (Ta * ea + Tb * eb)) / Sn;
+        const float da = oa - mu, db = ob - mu;
+        const float ca = 1e-6f * (oa - 1.f), cb = 1e-6f * (qb[i] - 1.f) ;    // sum e (d - o) of each part (band coordinates for B: the same number)
+        const float Vn = ea * (Va + da * (2.f * ca + da * Ea)) + eb * (Vb + db * (2.f * cb + db * Eb));
+        q[i] = mu;
+        v[i] = (1e-6f + Vn) / Sn;
         S[i] = Sn;
         m[i] = mn;
     }
@@ -161,8 +192,24 @@ int decnet_wide_forward(int mode, const float *ref, const float *tar, const floa
         return 0;
     };
     if (mode == 1) return sweep(1, disparity, var_out, sum_sim, max_cost);
-    CK(sweep(0, nullptr, out, sum_sim, max_cost));
-    if (mode == 2) CK(sweep(1, out, var_out, S2, m2));          // the fused call's variance is around its own disparity
+    if (mode == 0) return sweep(0, nullptr, out, sum_sim, max_cost);
+    // fused: one sweep of fused band calls (each band's variance around its own disparity), merged around the joint mean
+    (void)S2; (void)m2;
+    for (int b = 0; b < nb; ++b) {
+        const int d0 = b * Db, dw = (D - d0 < Db) ? D - d0 : Db;
+        if (!b) {
+            CK(decnet_mfma_forward(2, ref, tar, rmask, tmask, nullptr, out, var_out, sum_sim, max_cost, B, C, H, W, dw,
+                                   allow_compact, 0, stream));
+            continue;
+        }
+        hipLaunchKernelGGL(shift_planes, dim3(ew_grid(rowsF * W)), dim3(EW_THREADS), 0, stream, tar, Rb, rowsF, W, d0);
+        hipLaunchKernelGGL(shift_planes, dim3(ew_grid(np)), dim3(EW_THREADS), 0, stream, tmask, tmb, rowsM, W, d0);
+        LAUNCH_OK();
+        CK(decnet_mfma_forward(2, ref, Rb, rmask, tmb, nullptr, qb, db, Sb, mb, B, C, H, W, dw, allow_compact, 0, stream));
+        hipLaunchKernelGGL(merge_band_fused, dim3(ew_grid(np)), dim3(EW_THREADS), 0, stream, rmask, out, var_out, sum_sim,
+                           max_cost, qb, db, Sb, mb, np, (float)d0);
+        LAUNCH_OK();
+    }
     return 0;
 }
 
