@@ -101,7 +101,12 @@ def test_spavar_and_fused_forward_vs_oracle(dev, B, C, H, W, D, pr, pt):
 
 @pytest.mark.parametrize("B,C,H,W,D,pr,pt", [(2, 8, 4, 130, 48, 0.7, 0.7), (1, 24, 3, 81, 72, 0.9, 0.8),
                                              (1, 72, 4, 27, 24, 0.5, 0.5), (1, 8, 2, 300, 216, 1.0, 1.0),
-                                             (1, 5, 2, 9, 12, 1.0, 1.0)])
+                                             (1, 5, 2, 9, 12, 1.0, 1.0),
+                                             # the one-pass dense-row kernel with 2 / 3 channel blocks (round 6): odd widths
+                                             # (4-byte stores), channel counts that fill a block partly, the 16-tile ring
+                                             (1, 24, 3, 131, 72, 1.0, 1.0), (2, 13, 2, 101, 40, 1.0, 0.9),
+                                             (1, 20, 2, 210, 150, 1.0, 1.0), (1, 17, 3, 324, 72, 0.95, 0.95),
+                                             (1, 3, 2, 133, 30, 1.0, 1.0)])
 def test_backward_vs_oracle(dev, B, C, H, W, D, pr, pt):
     import decnet_amd
     L, R, rm, tm = make_case(13, B, C, H, W, pr, pt, relu=False, scale=0.5)
