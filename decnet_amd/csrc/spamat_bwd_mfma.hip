@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1015,13 +1017,18 @@ __global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : (CB == 3 && NT > 8) ? 2 :
         f32x4 gl[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) gl[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
+        // One band tile.  CHECK = the tile may lie outside the band (m >= NT) or left of the row (m > xt) and is then skipped
+        // by a wave-uniform branch.  Every such branch makes the compiler copy the window of right-gradient accumulators at
+        // its merge (16 - 20 v_mov per tile, round 6 ISA), so the steady state (xt >= NT - 1) runs the tiles that are always
+        // in band (4k + 3 < NT) without the test; the first NT - 1 left tiles and the last k keep it.
+        auto band_tile = [&](auto kc, auto checkc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr bool CHECK = decltype(checkc)::value;
             const int m = m0 + NW * k;
             // (wave-uniform) outside the band / left of the row.  Computing those tiles with all costs at -1e30 instead of
             // branching around them saves the 16 v_mov per tile the branch costs (the compiler copies the window of
             // right-gradient accumulators at every merge) but adds one tile in sixteen: measured 0.436 -> 0.46 ms, not kept.
-            if (m >= NT || m > xt) continue;
+            if (CHECK && (m >= NT || m > xt)) return;
             const int ob = ((xt - m) & (RING - 1)) * TILEB;
             const float4 bz = *reinterpret_cast<const float4 *>(BZ + ((xt - m) & (RING - 1)) * 16 + 4 * q);
             f32x4 cst = f32x4{bz.x, bz.y, bz.z, bz.w};
@@ -1082,6 +1089,20 @@ __global__ __launch_bounds__(64 * RB_NW, CB == 1 ? 4 : (CB == 3 && NT > 8) ? 2 :
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) gr[k][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        };
+        auto all_tiles = [&](auto steadyc) {
+            constexpr bool STEADY = decltype(steadyc)::value;
+            if constexpr (KS > 0) band_tile(std::integral_constant<int, 0>{}, std::integral_constant<bool, !(STEADY && 3 < NT)>{});
+            if constexpr (KS > 1) band_tile(std::integral_constant<int, 1>{}, std::integral_constant<bool, !(STEADY && 7 < NT)>{});
+            if constexpr (KS > 2) band_tile(std::integral_constant<int, 2>{}, std::integral_constant<bool, !(STEADY && 11 < NT)>{});
+            if constexpr (KS > 3) band_tile(std::integral_constant<int, 3>{}, std::integral_constant<bool, !(STEADY && 15 < NT)>{});
+        };
+        static_assert(KS <= 4, "all_tiles lists four tiles");
+        if constexpr (CB == 1) {                         // (CB > 1: two copies of the tile bodies spill registers)
+            if (xt >= NT - 1) all_tiles(std::true_type{});
+            else all_tiles(std::false_type{});
+        } else {
+            all_tiles(std::false_type{});
         }
         // this wave's share of the left tile's gradient -> LDS; summed in a fixed order by wave xt mod 4
 #pragma unroll
