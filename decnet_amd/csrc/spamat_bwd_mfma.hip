@@ -605,8 +605,10 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? 4 : 2)) void spamat_bwd_sparse
     // ---- 3. the two gradients
     const int j = lane & 15, q = lane >> 4;
     const int cj = j < CQ ? j : CQ - 1;               // channel this lane supplies to the contraction
-#pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
+    // (the side is a compile-time constant of two copies of this body: as a runtime loop variable every `side == 0 ? a : b`
+    // inside the tile loop stayed a v_cndmask -- 20 of its 58 vector instructions per tile, round 6 ISA)
+    auto one_side = [&](auto sidec) {
+        constexpr int side = decltype(sidec)::value;
         const int n_own = side == 0 ? nL : nR;
         const int *XO = side == 0 ? XL : XR;           // own positions
         const int *XT = side == 0 ? XR : XL;           // other positions
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? 4 : 2)) void spamat_bwd_sparse
                 for (int c = 0; c < C; ++c) grow[(size_t)c * plane + pp] = 0.f;
                 if (VAR && side == 0) grad_disp[rowpix + pp] = 0.f;
             }
-            continue;
+            return;
         }
         for (int e = 16 * wave; e < n_own; e += 16 * SB_NWAVE) {
             const bool act = e + j < n_own;
@@ -731,7 +733,9 @@ __global__ __launch_bounds__(NTHR, (NTHR == 256 ? 4 : 2)) void spamat_bwd_sparse
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-    }
+    };
+    one_side(std::integral_constant<int, 0>{});
+    one_side(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------
