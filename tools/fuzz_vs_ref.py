@@ -1,6 +1,6 @@
 """Random shapes, this repo's SpaMat / SpaVar kernels against the REFERENCE'S OWN kernels (oracle/_ref, built unmodified for
 gfx950 by oracle/ref_build.sh) on the same GPU: forward, fused forward, SpaMat backward, SpaVar backward.  Tolerances of
-tests/test_spamat_ref.py.  python tools/fuzz_vs_ref.py [first_seed [n_seeds [seconds]]]"""
+tests/test_spamat_ref.py.  python tools/fuzz_vs_ref.py [first_seed [n_seeds [seconds [wide]]]]   (wide: max_disp 273 .. 700)"""
 import os
 import sys
 import time
@@ -57,6 +57,7 @@ def truth_errors(L, Rt, rm, tm, D, ro, o, rmx, m):
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+WIDE = len(sys.argv) > 4 and sys.argv[4] == "wide"
 dev = torch.device("cuda:0")
 t0, bad, judged = time.time(), 0, 0
 done = 0
@@ -68,6 +69,9 @@ for seed in range(first, first + n):
     C = int(rng.choice([3, 8, 8, 8, 12, 24, 24, 40, 72]))
     W = int(rng.choice([rng.randint(5, 64), rng.randint(64, 400), 4 * rng.randint(20, 250), rng.randint(400, 1100)]))
     D = int(rng.choice([rng.randint(2, 30), 24, 72, 216, min(270, W + rng.randint(0, 40))]))
+    if WIDE:                            # max_disp above the band kernels' 272: csrc/spamat_wide.hip (bands + per-pixel merges)
+        D = int(rng.choice([rng.randint(273, 700), 405, 621, 273, 544, 545]))
+    kD = max(1.0, D / 216.0)            # absolute tolerances on disparity-sized values grow with the range
     B, H = int(rng.randint(1, 3)), int(rng.randint(1, 9))
     pr, pt = (float(rng.choice([0.0, 0.03, 0.1, 0.25, 0.5, 0.9, 1.0])) for _ in range(2))
     signed = bool(rng.randint(2))
@@ -94,9 +98,12 @@ for seed in range(first, first + n):
             e_ref, e_hip, m_ref, m_hip = truth_errors(L, Rt, rm, tm, D, ro, o, rmx, m)
             judged += 1
             assert e_hip <= 1.05 * e_ref + 1e-6, "disparity farther from float64 than the reference: %.3e vs %.3e" % (e_hip, e_ref)
-            assert m_hip <= 1.05 * m_ref + 2e-7, "max_cost farther from float64 than the reference: %.3e vs %.3e" % (m_hip, m_ref)
+            # (the primary gate on max_cost is 1e-6 relative, tests/test_spamat_ref.py: dense rows form the costs as bf16x3
+            # products, exact to ~3e-7 of a cost; the same allowance here)
+            m_tol = 1e-6 * max(1.0, float(rmx.abs().max()))
+            assert m_hip <= 1.05 * m_ref + 2e-7 + m_tol, "max_cost farther from float64 than the reference: %.3e vs %.3e" % (m_hip, m_ref)
             np.testing.assert_allclose(s.cpu().numpy(), fx["ssum"], rtol=1e-4, atol=1e-9)
-        np.testing.assert_allclose(v.cpu().numpy(), rv.cpu().numpy(), rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(v.cpu().numpy(), rv.cpu().numpy(), rtol=2e-4, atol=2e-3 * kD * kD)
         # the bit-packed mask entry (what the graph's mask kernel feeds): the same four planes, bit for bit
         try:
             bo = decnet_amd.spamatvar_forward_bits(L, Rt, pack_bits(rm), pack_bits(tm), D)
@@ -121,7 +128,7 @@ for seed in range(first, first + n):
         torch.cuda.synchronize()
         sc = max(t.gscale(vgl.cpu().numpy(), vgr.cpu().numpy()), float(vgd.abs().max()))
         for a, b, nm in ((hl, vgl, "var grad_ref"), (hr, vgr, "var grad_tar"), (hd, vgd, "var grad_disparity")):
-            assert float((a - b).abs().max()) < 6e-5 * sc, nm
+            assert float((a - b).abs().max()) < 6e-5 * sc * kD, nm
     except AssertionError as e:
         bad += 1
         import traceback
