@@ -86,17 +86,17 @@ __host__ __device__ constexpr int bwd_nown(int side, bool var) { return side == 
 
 // planes: 0 bias (0 / -1e30 of the other side's mask); SIDE 1 adds 1 -max*log2e, 2 out, 3 g/S, 4 mu
 template <int NT, bool VAR, int KQ, int SIDE>
-__global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
+__device__ __forceinline__ void bwd_band_side(
     const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
     const float *__restrict__ tmask, const float *__restrict__ disparity,
     const float *__restrict__ out, const float *__restrict__ sum_sim,
     const float *__restrict__ max_cost, const float *__restrict__ grad_out,
     float *__restrict__ grad_own, float *__restrict__ grad_disp, int C, int H, int W, int D,
-    int segs_per_row, int XT, int marker) {
+    int segs_per_row, int XT, int marker, const int blk) {
     // marker: this launch follows spamat_bwd_sparse, which left BWD_MARK in channel 0 of grad_own at
     // the first pixel of every segment of exactly the rows it did not take
     if (marker) {
-        const int sg = blockIdx.x % segs_per_row, rw = blockIdx.x / segs_per_row;
+        const int sg = blk % segs_per_row, rw = blk / segs_per_row;
         const size_t at = ((size_t)(rw / H) * C * H + (rw % H)) * W + (size_t)sg * (XT * 16);
         if (__float_as_int(grad_own[at]) != BWD_MARK) return;
     }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
     const int SW = lo.SW, HALO = lo.HALO, OW = lo.OW, OP = lo.OP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg = blockIdx.x % segs_per_row, row = blockIdx.x / segs_per_row;
+    const int seg = blk % segs_per_row, row = blk / segs_per_row;
     const int b = row / H, y = row - b * H;
     const int xs = seg * SW;
     const int xo0 = SIDE == 0 ? xs - HALO : xs;      // image x of staged column 0
@@ -404,6 +404,26 @@ __global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
     }
 }
 
+// Both sides from one launch (round 6): workgroups [0, n0) own left pixels (grad_ref, grad_disp), the rest right pixels
+// (grad_tar).  As two launches each side left most of the chip idle at the small stages (stage 1: 240 workgroups of one
+// latency chain each, 15 us + 15 us back to back); together they overlap.
+template <int NT, bool VAR, int KQ>
+__global__ __launch_bounds__(THREADS, 4) void spamat_bwd_mfma(
+    const float *__restrict__ ref, const float *__restrict__ tar, const float *__restrict__ rmask,
+    const float *__restrict__ tmask, const float *__restrict__ disparity,
+    const float *__restrict__ out, const float *__restrict__ sum_sim,
+    const float *__restrict__ max_cost, const float *__restrict__ grad_out,
+    float *__restrict__ grad_ref, float *__restrict__ grad_tar, float *__restrict__ grad_disp, int C, int H, int W,
+    int D, int n0, int segs0, int XT0, int segs1, int XT1, int marker) {
+    const int blk = blockIdx.x;
+    if (blk < n0)
+        bwd_band_side<NT, VAR, KQ, 0>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out, grad_ref,
+                                      grad_disp, C, H, W, D, segs0, XT0, marker, blk);
+    else
+        bwd_band_side<NT, VAR, KQ, 1>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out, grad_tar,
+                                      nullptr, C, H, W, D, segs1, XT1, marker, blk - n0);
+}
+
 // tiles per segment of the band kernel for one side (0 = does not fit)
 template <int NT, bool VAR, int SIDE>
 int side_xt(int cq, int W) {
@@ -424,22 +444,25 @@ int side_xt(int cq, int W) {
     return bytes(XT) > budget1 ? 0 : XT;
 }
 
-template <int NT, bool VAR, int KQ, int SIDE>
-int launch_side(const float *ref, const float *tar, const float *rmask, const float *tmask,
-                const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
-                const float *grad_out, float *grad_own, float *grad_disp, int B, int C, int H, int W,
-                int D, int XT, int marker, hipStream_t stream) {
-    constexpr int NPL = SIDE == 0 ? 1 : (VAR ? 5 : 4);
-    const size_t lds = (size_t)4 * make_blayout(4 * KQ, NT, XT, NPL, bwd_nown(SIDE, VAR)).total;
-    const int segs = ceil_div(ceil_div(W, 16), XT);
+template <int NT, bool VAR, int KQ>
+int launch_sides(const float *ref, const float *tar, const float *rmask, const float *tmask,
+                 const float *disparity, const float *out, const float *sum_sim, const float *max_cost,
+                 const float *grad_out, float *grad_ref, float *grad_tar, float *grad_disp, int B, int C, int H,
+                 int W, int D, int XT0, int XT1, int marker, hipStream_t stream) {
+    const size_t lds0 = (size_t)4 * make_blayout(4 * KQ, NT, XT0, 1, bwd_nown(0, VAR)).total;
+    const size_t lds1 = (size_t)4 * make_blayout(4 * KQ, NT, XT1, VAR ? 5 : 4, bwd_nown(1, VAR)).total;
+    const size_t lds = lds0 > lds1 ? lds0 : lds1;
+    const int segs0 = ceil_div(ceil_div(W, 16), XT0), segs1 = ceil_div(ceil_div(W, 16), XT1);
+    const size_t n0 = (size_t)B * H * segs0, n1 = (size_t)B * H * segs1;
+    if (n0 + n1 >= 2147483648ull) return DECNET_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)spamat_bwd_mfma<NT, VAR, KQ, SIDE>,
+        hipError_t e = hipFuncSetAttribute((const void *)spamat_bwd_mfma<NT, VAR, KQ>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((spamat_bwd_mfma<NT, VAR, KQ, SIDE>), dim3((unsigned)((size_t)B * H * segs)),
-                       dim3(THREADS), lds, stream, ref, tar, rmask, tmask, disparity, out, sum_sim,
-                       max_cost, grad_out, grad_own, grad_disp, C, H, W, D, segs, XT, marker);
+    hipLaunchKernelGGL((spamat_bwd_mfma<NT, VAR, KQ>), dim3((unsigned)(n0 + n1)), dim3(THREADS), lds, stream, ref,
+                       tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out, grad_ref, grad_tar, grad_disp, C,
+                       H, W, D, (int)n0, segs0, XT0, segs1, XT1, marker);
     return decnet_launch_status();
 }
 
@@ -1209,7 +1232,7 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
             }
         }
     }
-    // dense rows at C <= 8 (SpaMat): both gradients from one pass, four waves per row (the two band launches below stay
+    // dense rows at C <= 8 (SpaMat): both gradients from one pass, four waves per row (the band launch below stays
     // the path of SpaVar, of C > 8 and of rows narrower than the band)
     if constexpr (KQ == 2 && !VAR && NT <= 15) {
         if (W >= 16 * NT)
@@ -1226,11 +1249,8 @@ int launch_both(const float *ref, const float *tar, const float *rmask, const fl
             if (rc != DECNET_ERR_UNSUPPORTED) return rc;
         }
     }
-    int rc = launch_side<NT, VAR, KQ, 0>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
-                                         grad_out, grad_ref, grad_disp, B, C, H, W, D, xt0, marker, stream);
-    if (rc) return rc;
-    return launch_side<NT, VAR, KQ, 1>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost,
-                                       grad_out, grad_tar, nullptr, B, C, H, W, D, xt1, marker, stream);
+    return launch_sides<NT, VAR, KQ>(ref, tar, rmask, tmask, disparity, out, sum_sim, max_cost, grad_out, grad_ref,
+                                     grad_tar, grad_disp, B, C, H, W, D, xt0, xt1, marker, stream);
 }
 
 template <int NT, bool VAR>
