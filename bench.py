@@ -85,11 +85,13 @@ def make_inputs(B, dev, density, seed):
     return feats, masks
 
 
-def make_regularizer(C, dev, seed=17):
+def make_regularizer(C, dev, seed=17, cost_func="cor"):
     """Random-init CostRegNetNoDown (conv init as SparseDenseNetRefinementMask.py:248-250)."""
     import decnet_amd
-    reg = decnet_amd.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func="cor")
+    reg = decnet_amd.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func=cost_func)
     g = torch.Generator().manual_seed(seed)
+    if cost_func == "cat":
+        reg.conv_pre.weight.data.normal_(0, math.sqrt(2.0 / C), generator=g)
     for u in reg.units():
         co = u.conv.weight.shape[0]
         u.conv.weight.data.normal_(0, math.sqrt(2.0 / (27 * co)), generator=g)
@@ -391,6 +393,20 @@ def live_traffic(config):
         return None, "%s: %s" % (type(e).__name__, e)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cost_func_leg(feats, dev, iters=20):
+    """The stage-0 branch (decnet_stage0_forward_cf) with each --cost_func of the reference (submodule.py:552-560) on the
+    step's own stage-0 feature maps: "cor" is what demo.sh / eval.sh pass and what `value` is measured with; "ssd" changes
+    the per-voxel arithmetic of the head kernel, "cat" adds conv_pre (two C x C products over the feature maps)."""
+    import decnet_amd
+    L, R = feats
+    out = {}
+    for cf in ("cor", "ssd", "cat"):
+        st = decnet_amd.Stage0(make_regularizer(L.shape[1], dev, cost_func=cf))
+        with torch.no_grad():
+            out[cf + "_ms"] = round(time_kernel(lambda: st(L, R, STAGES[0][3]), iters, warm=5), 4)
+    return out
 
 
 def alt_gemm_leg():
@@ -1370,6 +1386,11 @@ def main():
         if (world == 1 and not args.no_alt and args.config == 2 and args.mask_density >= 1.0 and
                 os.environ.get("DECNET_WINO_GEMM", "") == ""):
             out["alt_wino_gemm_fp32"] = alt_gemm_leg()
+        if world == 1 and not args.no_alt:
+            try:
+                out["stage0_cost_funcs"] = cost_func_leg(hp.feats[0], dev)
+            except Exception as e:                      # never lose the bench line to an extra leg
+                out["stage0_cost_funcs"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)
         print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)

@@ -23,6 +23,8 @@ SIGNATURES = {
     "decnet_spamatvar_forward": [_P] * 8 + [_I] * 5 + [_P],
     "decnet_spamatvar_forward_bits": [_P] * 8 + [_I] * 5 + [_P],
     "decnet_costvol_forward": [_P] * 3 + [_I] * 5 + [_P],
+    "decnet_costvol_forward_cf": [_P] * 3 + [_I] * 6 + [_P],
+    "decnet_conv3d_pointwise": [_P] * 3 + [_I] * 6 + [_P],
     "decnet_conv3d_packed_cout": [_I],
     "decnet_conv3d_pack_weight": [_P, _P, _I, _I, _P],
     "decnet_conv3d_bn_act": [_P] * 6 + [_I] * 7 + [_P],
@@ -34,6 +36,7 @@ SIGNATURES = {
     "decnet_conv3d_wino_stack_workspace_floats": [_I] * 6,
     "decnet_conv3d_wino_stack_bn_act": [_P] * 4 + [_I] * 3 + [_P] * 2 + [_I] * 6 + [_P],
     "decnet_costvol_wino_stack_bn_act": [_P] * 5 + [_I] * 3 + [_P] * 2 + [_I] * 6 + [_P],
+    "decnet_costvol_wino_stack_bn_act_cf": [_P] * 5 + [_I] * 3 + [_P] * 2 + [_I] * 7 + [_P],
     "decnet_conv3d_cout1_softargmax": [_P, _P, _F, _F, _P, _P] + [_I] * 5 + [_P],
     "decnet_conv2d_packed_floats": [_I] * 4,
     "decnet_conv2d_pack_weight": [_P, _P] + [_I] * 4 + [_P],
@@ -66,6 +69,8 @@ SIGNATURES = {
     "decnet_disparity_regression": [_P] * 3 + [_I] * 4 + [_P],
     "decnet_stage0_workspace_floats": [_I] * 6,
     "decnet_stage0_forward": [_P] * 6 + [_I] * 6 + [_P],
+    "decnet_stage0_cf_workspace_floats": [_I] * 7,
+    "decnet_stage0_forward_cf": [_P] * 7 + [_I] * 7 + [_P],
     "decnet_ncdhw_to_ndhwc": [_P, _P] + [_I] * 5 + [_P],
     "decnet_ndhwc_to_ncdhw": [_P, _P] + [_I] * 5 + [_P],
 }
@@ -91,6 +96,7 @@ class DecnetHipError(RuntimeError):
 
 
 UNSUPPORTED = -3          # DECNET_ERR_UNSUPPORTED: valid arguments the gfx950 kernels of that entry do not cover
+COST_FUNC = {"cor": 0, "ssd": 1, "cat": 2, "sum": 3}          # DECNET_COST_* of include/decnet_hip.h
 
 
 def lib():

@@ -661,6 +661,8 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
 // values -- the same fp32 operation sequence, fp contraction off -- are formed for one sample x four channels straight
 // into the LDS volume of wino_mid_transform, and that kernel's phase 2 writes their B^T transforms as V (quad major).
 // The bilinear coordinates depend on x - d and on y only: two small LDS tables (W + D and H entries).
+// CF: the cost function (common.h:decnet_cost: cor, ssd, or sum = the "cat" volume behind conv_pre).
+template <int CF>
 __global__ __launch_bounds__(MID_THREADS) void wino_head_transform(
     const float *__restrict__ left, const float *__restrict__ right, float *__restrict__ V, Tiling g, int C, int nt) {
 #pragma clang fp contract(off)
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(MID_THREADS) void wino_head_transform(
             if (vy0 && vx1) rr += a01 * w01;
             if (vy1 && vx0) rr += a10 * w10;
             if (vy1 && vx1) rr += a11 * w11;
-            cell[d * H * 4 * Wp] = l * rr;              // submodule.py:521
+            cell[d * H * 4 * Wp] = decnet_cost<CF>(l, rr);   // submodule.py:511-530
         }
     }
     __syncthreads();
@@ -1244,7 +1246,7 @@ size_t head_lds_bytes(int D, int H, int W) {
 int conv_stack(const float *x, const float *left, const float *right, const float *const *u,
                const float *const *scale, const float *const *shift,
                int n_layers, int res_src, int res_dst, float *y, float *workspace, float *R, int B, int D, int H,
-               int W, int C, hipStream_t s) {
+               int W, int C, hipStream_t s, int cost_func = DECNET_COST_COR) {
     constexpr int NP = 216;
     Tiling g{D, H, W, ceil_div(D, 4), ceil_div(H, 4), ceil_div(W, 4)};
     const int nt = B * g.Td * g.Th * g.Tw;
@@ -1262,12 +1264,20 @@ int conv_stack(const float *x, const float *left, const float *right, const floa
                            dim3(ith), 0, s, x, V, g, C, 0, nt, bytes);
     } else {
         const size_t hl = head_lds_bytes(D, H, W);
-        if (hipFuncSetAttribute((const void *)wino_head_transform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl) != hipSuccess) {
+        const void *fn = cost_func == DECNET_COST_COR   ? (const void *)wino_head_transform<DECNET_COST_COR>
+                         : cost_func == DECNET_COST_SSD ? (const void *)wino_head_transform<DECNET_COST_SSD>
+                                                        : (const void *)wino_head_transform<DECNET_COST_SUM>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl) != hipSuccess) {
             (void)hipGetLastError();
             return DECNET_ERR_UNSUPPORTED;
         }
-        hipLaunchKernelGGL(wino_head_transform, dim3((unsigned)(B * ((C + 3) / 4))), dim3(MID_THREADS), hl, s, left, right, V,
-                           g, C, nt);
+        const dim3 grid((unsigned)(B * ((C + 3) / 4)));
+        if (cost_func == DECNET_COST_COR)
+            hipLaunchKernelGGL(wino_head_transform<DECNET_COST_COR>, grid, dim3(MID_THREADS), hl, s, left, right, V, g, C, nt);
+        else if (cost_func == DECNET_COST_SSD)
+            hipLaunchKernelGGL(wino_head_transform<DECNET_COST_SSD>, grid, dim3(MID_THREADS), hl, s, left, right, V, g, C, nt);
+        else
+            hipLaunchKernelGGL(wino_head_transform<DECNET_COST_SUM>, grid, dim3(MID_THREADS), hl, s, left, right, V, g, C, nt);
     }
     int rc = decnet_launch_status();
     if (rc) return rc;
@@ -1422,8 +1432,18 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
                                      const float *const *scale, const float *const *shift, int n_layers, int res_src,
                                      int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
                                      int variant, void *stream) {
+    return decnet_costvol_wino_stack_bn_act_cf(left, right, u, scale, shift, n_layers, res_src, res_dst, y, workspace, B, C, H,
+                                               W, D, variant, DECNET_COST_COR, stream);
+}
+
+int decnet_costvol_wino_stack_bn_act_cf(const float *left, const float *right, const float *const *u,
+                                        const float *const *scale, const float *const *shift, int n_layers, int res_src,
+                                        int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
+                                        int variant, int cost_func, void *stream) {
     if (!left || !right || !u || !scale || !shift || !y || !workspace) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || D < 1 || H < 1 || W < 1 || C < 1 || n_layers < 1) return DECNET_ERR_BAD_SHAPE;
+    if (cost_func != DECNET_COST_COR && cost_func != DECNET_COST_SSD && cost_func != DECNET_COST_SUM)
+        return DECNET_ERR_BAD_SHAPE;
     if (H < 2 || W < 2) return DECNET_ERR_UNSUPPORTED;   // the stretched warp of one row / column: per-layer path
     for (int i = 0; i < n_layers; ++i)
         if (!u[i] || !scale[i] || !shift[i]) return DECNET_ERR_NULL_POINTER;
@@ -1434,7 +1454,7 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
         return DECNET_ERR_UNSUPPORTED;
     const size_t w = (decnet_conv3d_wino_workspace_floats(B, D, H, W, C, C, variant) + 63) & ~(size_t)63;
     return conv_stack(nullptr, left, right, u, scale, shift, n_layers, res_src, res_dst, y, workspace, workspace + w, B, D, H,
-                      W, C, (hipStream_t)stream);
+                      W, C, (hipStream_t)stream, cost_func);
 }
 
 int decnet_conv3d_wino_bn_act(const float *x, const float *u, const float *scale, const float *shift,

@@ -34,10 +34,13 @@ constexpr int B_PITCH = 240;   // == 16 (mod 32): rows kq, kq+1 land on opposite
 // One workgroup per (b, y): the left row and the two right rows the bilinear taps touch are read
 // once, x-contiguous (NCHW), into LDS; every (d, x, c) product is then formed from LDS and
 // written c-contiguous (channels-last), so both HBM sides are coalesced.
-__global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict__ left,
-                                                         const float *__restrict__ right,
-                                                         float *__restrict__ cost, int C, int H,
-                                                         int W, int D, int dchunk, int cgn) {
+// CF: the cost function (common.h:decnet_cost); DECNET_COST_CAT writes the masked left value at channel c and the warped
+// right value at channel C + c of a 2 C channel volume (submodule.py:514).
+template <int CF>
+__global__ __launch_bounds__(512) void costvol_ndhwc(const float *__restrict__ left,
+                                                     const float *__restrict__ right,
+                                                     float *__restrict__ cost, int C, int H,
+                                                     int W, int D, int dchunk, int cgn) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int WP = W | 1;                      // odd pitch: column reads across c are conflict-free
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
     __syncthreads();
     // blockIdx.y picks a chunk of disparities (more workgroups than the B*H rows alone)
     const int d_lo = blockIdx.y * dchunk, d_hi = min(D, d_lo + dchunk);
-    float *out = cost + (size_t)b * D * plane * C + (size_t)y * W * C + c_lo;     // + d*plane*C + x*C + c
+    const int CO = CF == DECNET_COST_CAT ? 2 * C : C;                              // channels of the volume
+    float *out = cost + (size_t)b * D * plane * CO + (size_t)y * W * CO + c_lo;   // + d*plane*CO + x*CO + c
     for (int t = d_lo * W + wave; t < d_hi * W; t += nwaves) {
         const int d = t / W, x = t - d * W;                       // wave-uniform
         float cx = (float)(x - d) / ((float)(W - 1.0) / 2.0f) - 1.0f;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
         float wx1 = ix - fx, wx0 = 1.0f - wx1;
         bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
         const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
-        float *o = out + (size_t)d * plane * C + (size_t)x * C;
+        float *o = out + (size_t)d * plane * CO + (size_t)x * CO;
         for (int c = lane; c < CN; c += 64) {
             float l = x >= d ? Ls[c * WP + x] : 0.f;              // submodule.py:506-508
             float r = 0.f;                                        // same tap order as grid_sample
@@ -103,7 +107,79 @@ __global__ __launch_bounds__(512) void costvol_cor_ndhwc(const float *__restrict
             if (vy0 && vx1) r += R0[c * WP + x1] * w01;
             if (vy1 && vx0) r += R1[c * WP + x0] * w10;
             if (vy1 && vx1) r += R1[c * WP + x1] * w11;
-            o[c] = l * r;                                         // submodule.py:521
+            if (CF == DECNET_COST_CAT) {
+                o[c] = l;
+                o[C + c] = r;
+            } else {
+                o[c] = decnet_cost<CF>(l, r);                     // submodule.py:511-530
+            }
+        }
+    }
+}
+
+// ----------------------------- Conv3d kernel 1 (conv_pre) ------------------------------
+// y[b, co, p] = sum_ci w[co][ci] x[b, ci, p]   (CL = false: x [B][Ci][P], y [B][Co][P]; CL = true: x [B][P][Ci],
+// y [B][P][Co]): CostRegNetNoDown.conv_pre of cost_func "cat" (submodule.py:618-619: Conv3d(2 C, C, 1), no bias).  A
+// workgroup owns PW_TP positions: their Ci inputs in LDS, the weights through LDS in chunks of 32 input channels
+// (transposed, so that a lane's read is its own output channel), thread = output channel, PW_TP accumulators; the
+// sum over ci is one fp32 fma chain in channel order.
+constexpr int PW_TP = 32, PW_CK = 32, PW_THREADS = 256;
+template <bool CL>
+__global__ __launch_bounds__(PW_THREADS) void pointwise_conv(const float *__restrict__ x, const float *__restrict__ w,
+                                                            float *__restrict__ y, int Ci, int Co, int P, int ldw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;                              // [Ci][PW_TP]
+    const int WP = min(Co, PW_THREADS) | 1;
+    float *Ws = smem + (size_t)Ci * PW_TP;          // [PW_CK][WP]
+    const int b = blockIdx.y, p0 = blockIdx.x * PW_TP, np = min(PW_TP, P - p0);
+    const float *xb = x + (size_t)b * Ci * P;
+    float *yb = y + (size_t)b * Co * P;
+    if (CL) {
+        for (int i = threadIdx.x; i < Ci * PW_TP; i += PW_THREADS) {
+            const int pp = i / Ci, ci = i - pp * Ci;                     // consecutive lanes: consecutive channels
+            Xs[ci * PW_TP + pp] = pp < np ? xb[(size_t)(p0 + pp) * Ci + ci] : 0.f;
+        }
+    } else {
+        for (int i = threadIdx.x; i < Ci * PW_TP; i += PW_THREADS) {
+            const int ci = i / PW_TP, pp = i - ci * PW_TP;               // consecutive lanes: consecutive positions
+            Xs[i] = pp < np ? xb[(size_t)ci * P + p0 + pp] : 0.f;
+        }
+    }
+    for (int co0 = 0; co0 < Co; co0 += PW_THREADS) {
+        const int co = co0 + threadIdx.x;
+        float acc[PW_TP];
+#pragma unroll
+        for (int j = 0; j < PW_TP; ++j) acc[j] = 0.f;
+        for (int c0 = 0; c0 < Ci; c0 += PW_CK) {
+            __syncthreads();                                             // Xs written / the previous chunk's Ws read
+            for (int i = threadIdx.x; i < PW_CK * min(PW_THREADS, Co - co0); i += PW_THREADS) {
+                const int r = i / PW_CK, k = i - r * PW_CK;              // 32 consecutive input channels of one row
+                Ws[k * WP + r] = c0 + k < Ci ? w[(size_t)(co0 + r) * ldw + c0 + k] : 0.f;
+            }
+            __syncthreads();
+            if (co < Co) {
+                const int kn = min(PW_CK, Ci - c0);
+                for (int k = 0; k < kn; ++k) {
+                    const float wv = Ws[k * WP + threadIdx.x];
+                    const float4 *xr = reinterpret_cast<const float4 *>(Xs + (size_t)(c0 + k) * PW_TP);
+#pragma unroll
+                    for (int j = 0; j < PW_TP / 4; ++j) {
+                        const float4 v = xr[j];                          // the same address in every lane: broadcast
+                        acc[4 * j] = fmaf(wv, v.x, acc[4 * j]);
+                        acc[4 * j + 1] = fmaf(wv, v.y, acc[4 * j + 1]);
+                        acc[4 * j + 2] = fmaf(wv, v.z, acc[4 * j + 2]);
+                        acc[4 * j + 3] = fmaf(wv, v.w, acc[4 * j + 3]);
+                    }
+                }
+            }
+        }
+        if (co < Co) {
+#pragma unroll
+            for (int j = 0; j < PW_TP; ++j)
+                if (j < np) {
+                    if (CL) yb[(size_t)(p0 + j) * Co + co] = acc[j];
+                    else yb[(size_t)co * P + p0 + j] = acc[j];
+                }
         }
     }
 }
@@ -507,9 +583,16 @@ extern "C" {
 
 int decnet_costvol_forward(const float *left, const float *right, float *cost, int B, int C, int H,
                            int W, int D, void *stream) {
+    return decnet_costvol_forward_cf(left, right, cost, B, C, H, W, D, DECNET_COST_COR, stream);
+}
+
+int decnet_costvol_forward_cf(const float *left, const float *right, float *cost, int B, int C, int H,
+                              int W, int D, int cost_func, void *stream) {
     if (!left || !right || !cost) return DECNET_ERR_NULL_POINTER;
-    if (B < 1 || C < 1 || H < 2 || W < 2 || D < 1) return DECNET_ERR_BAD_SHAPE;
-    if ((double)B * D * H * W * C >= 1099511627776.0 || (double)D * W * C >= 2147483648.0 ||
+    if (B < 1 || C < 1 || H < 2 || W < 2 || D < 1 || cost_func < DECNET_COST_COR || cost_func > DECNET_COST_SUM)
+        return DECNET_ERR_BAD_SHAPE;
+    const int CO = cost_func == DECNET_COST_CAT ? 2 * C : C;
+    if ((double)B * D * H * W * CO >= 1099511627776.0 || (double)D * W * CO >= 2147483648.0 ||
         (double)B * H >= 2147483648.0)
         return DECNET_ERR_BAD_SHAPE;
     // channel groups of <= 128, equal sizes: 216 -> 2 x 108 with 4 disparities per workgroup measured best
@@ -517,18 +600,47 @@ int decnet_costvol_forward(const float *left, const float *right, float *cost, i
     const int groups = ceil_div(C, 128), cgn = ceil_div(C, groups);
     size_t lds = (size_t)3 * cgn * (W | 1) * 4;
     if (lds > DECNET_LDS_BYTES - 1024) return DECNET_ERR_UNSUPPORTED;
+    const void *fn = cost_func == DECNET_COST_COR   ? (const void *)costvol_ndhwc<DECNET_COST_COR>
+                     : cost_func == DECNET_COST_SSD ? (const void *)costvol_ndhwc<DECNET_COST_SSD>
+                     : cost_func == DECNET_COST_CAT ? (const void *)costvol_ndhwc<DECNET_COST_CAT>
+                                                    : (const void *)costvol_ndhwc<DECNET_COST_SUM>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)costvol_cor_ndhwc,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     // disparities per workgroup: the row staging (3 x C x W floats, three dependent load batches) is the
     // expensive part, so a workgroup keeps its rows for as many d as still leaves >= ~1 workgroup per CU
     int dchunk = 1;
     while (dchunk < D && (long)B * H * ceil_div(C, cgn) * ceil_div(D, 2 * dchunk) >= 512) dchunk *= 2;
-    hipLaunchKernelGGL(costvol_cor_ndhwc, dim3((unsigned)(B * H), (unsigned)ceil_div(D, dchunk),
-                                               (unsigned)ceil_div(C, cgn)),
-                       dim3(512), lds, (hipStream_t)stream, left, right, cost, C, H, W, D, dchunk, cgn);
+    const dim3 grid((unsigned)(B * H), (unsigned)ceil_div(D, dchunk), (unsigned)ceil_div(C, cgn));
+#define GO(CF)                                                                                                    \
+    hipLaunchKernelGGL(costvol_ndhwc<CF>, grid, dim3(512), lds, (hipStream_t)stream, left, right, cost, C, H, W, D, \
+                       dchunk, cgn)
+    if (cost_func == DECNET_COST_COR) GO(DECNET_COST_COR);
+    else if (cost_func == DECNET_COST_SSD) GO(DECNET_COST_SSD);
+    else if (cost_func == DECNET_COST_CAT) GO(DECNET_COST_CAT);
+    else GO(DECNET_COST_SUM);
+#undef GO
+    return decnet_launch_status();
+}
+
+int decnet_conv3d_pointwise(const float *x, const float *w, float *y, int B, int Ci, int Co, int P, int ldw,
+                            int channels_last, void *stream) {
+    if (!x || !w || !y) return DECNET_ERR_NULL_POINTER;
+    if (B < 1 || Ci < 1 || Co < 1 || P < 1 || ldw < Ci) return DECNET_ERR_BAD_SHAPE;
+    if (B > 65535 || (double)P * (Ci > Co ? Ci : Co) >= 2147483648.0 * 2) return DECNET_ERR_BAD_SHAPE;
+    const size_t lds = ((size_t)Ci * PW_TP + (size_t)PW_CK * ((Co < PW_THREADS ? Co : PW_THREADS) | 1)) * 4;
+    if (lds > DECNET_LDS_BYTES - 1024) return DECNET_ERR_UNSUPPORTED;
+    const void *fn = channels_last ? (const void *)pointwise_conv<true> : (const void *)pointwise_conv<false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid((unsigned)((P + PW_TP - 1) / PW_TP), (unsigned)B);
+    if (channels_last)
+        hipLaunchKernelGGL(pointwise_conv<true>, grid, dim3(PW_THREADS), lds, (hipStream_t)stream, x, w, y, Ci, Co, P, ldw);
+    else
+        hipLaunchKernelGGL(pointwise_conv<false>, grid, dim3(PW_THREADS), lds, (hipStream_t)stream, x, w, y, Ci, Co, P, ldw);
     return decnet_launch_status();
 }
 

@@ -17,6 +17,13 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 extern "C" {
 
+size_t decnet_stage0_cf_workspace_floats(int B, int C, int H, int W, int D, int variant, int cost_func) {
+    if (cost_func != DECNET_COST_COR && cost_func != DECNET_COST_SSD && cost_func != DECNET_COST_CAT) return 0;
+    const size_t n = decnet_stage0_workspace_floats(B, C, H, W, D, variant);
+    // "cat": the two feature maps behind their halves of conv_pre
+    return n && cost_func == DECNET_COST_CAT ? n + 2 * align64((size_t)B * C * H * W) : n;
+}
+
 size_t decnet_stage0_workspace_floats(int B, int C, int H, int W, int D, int variant) {
     if (B < 1 || C < 1 || H < 1 || W < 1 || D < 1 || variant < -1 || variant > 3) return 0;
     if (variant < 0) variant = auto_variant(D);
@@ -38,13 +45,23 @@ size_t decnet_stage0_workspace_floats(int B, int C, int H, int W, int D, int var
 int decnet_stage0_forward(const float *left, const float *right, const decnet_stage0_params *p,
                           float *workspace, float *reg, float *pred, int B, int C, int H, int W, int D,
                           int variant, void *stream) {
+    return decnet_stage0_forward_cf(left, right, p, nullptr, workspace, reg, pred, B, C, H, W, D, variant, DECNET_COST_COR,
+                                    stream);
+}
+
+int decnet_stage0_forward_cf(const float *left, const float *right, const decnet_stage0_params *p, const float *w_pre,
+                             float *workspace, float *reg, float *pred, int B, int C, int H, int W, int D,
+                             int variant, int cost_func, void *stream) {
     if (!left || !right || !p || !workspace || !pred || !p->w_last) return DECNET_ERR_NULL_POINTER;
+    if (cost_func != DECNET_COST_COR && cost_func != DECNET_COST_SSD && cost_func != DECNET_COST_CAT)
+        return DECNET_ERR_BAD_SHAPE;
+    if (cost_func == DECNET_COST_CAT && !w_pre) return DECNET_ERR_NULL_POINTER;
     for (int i = 0; i < 7; ++i)
         if (!p->w[i] || !p->scale[i] || !p->shift[i]) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || C < 1 || H < 1 || W < 1 || D < 1 || variant < -1 || variant > 3) return DECNET_ERR_BAD_SHAPE;
     if (C % 4) return DECNET_ERR_UNSUPPORTED;          // channel counts move in 16-byte groups (pad to x4)
     if (variant < 0) variant = auto_variant(D);
-    if (!decnet_stage0_workspace_floats(B, C, H, W, D, variant)) return DECNET_ERR_UNSUPPORTED;
+    if (!decnet_stage0_cf_workspace_floats(B, C, H, W, D, variant, cost_func)) return DECNET_ERR_UNSUPPORTED;
     const size_t act = align64((size_t)B * D * H * W * C);
     float *cv = workspace, *a = cv + act, *b = a + act, *c = b + act, *ws = c + act;
     const size_t stack = variant <= 2 ? decnet_conv3d_wino_stack_workspace_floats(B, D, H, W, C, variant) : 0;
@@ -53,10 +70,24 @@ int decnet_stage0_forward(const float *left, const float *right, const decnet_st
     const size_t last = decnet_conv3d_cout1_workspace_floats(B, D, H, W);
     float *t_last = last > act ? ws + wino : a;
 
-    int rc = DECNET_ERR_UNSUPPORTED;
+    int rc;
+    int cf = cost_func;
+    if (cost_func == DECNET_COST_CAT) {
+        // conv_pre(cat(left_vol, right_vol)) (submodule.py:514, 651-652) = SUM volume of (W_l left, W_r right): the 1x1x1
+        // convolution is per voxel and linear, the warp (bilinear, zero padded) and the x >= d mask are per channel
+        if (H < 1 || W < 1 || (double)H * W >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
+        const size_t fm = align64((size_t)B * C * H * W);
+        float *pl = ws + wino + (last > act ? align64(last) : 0), *pr = pl + fm;
+        if ((rc = decnet_conv3d_pointwise(left, w_pre, pl, B, C, C, H * W, 2 * C, 0, stream))) return rc;
+        if ((rc = decnet_conv3d_pointwise(right, w_pre + C, pr, B, C, C, H * W, 2 * C, 0, stream))) return rc;
+        left = pl;
+        right = pr;
+        cf = DECNET_COST_SUM;
+    }
+    rc = DECNET_ERR_UNSUPPORTED;
     if (stack)      // cost volume + all seven layers, neither the volume nor the activations between the layers in HBM
-        rc = decnet_costvol_wino_stack_bn_act(left, right, p->w, p->scale, p->shift, 7, 1, 4, c, ws, B, C, H, W, D, variant,
-                                              stream);
+        rc = decnet_costvol_wino_stack_bn_act_cf(left, right, p->w, p->scale, p->shift, 7, 1, 4, c, ws, B, C, H, W, D,
+                                                 variant, cf, stream);
     if (rc == DECNET_OK) {
         if (C <= 256 && D <= 256)
             return decnet_conv3d_cout1_softargmax_ws(c, p->w_last, p->scale_last, p->shift_last, reg, pred, t_last, B,
@@ -65,7 +96,7 @@ int decnet_stage0_forward(const float *left, const float *right, const decnet_st
                                               stream);
     }
     if (rc != DECNET_ERR_UNSUPPORTED) return rc;
-    if ((rc = decnet_costvol_forward(left, right, cv, B, C, H, W, D, stream))) return rc;
+    if ((rc = decnet_costvol_forward_cf(left, right, cv, B, C, H, W, D, cf, stream))) return rc;
     auto conv = [&](int i, const float *src, float *dst, const float *res) {
         if (variant <= 2)
             return decnet_conv3d_wino_bn_act(src, p->w[i], p->scale[i], p->shift[i], res, dst, ws, B, D, H, W, C, C,

@@ -70,7 +70,7 @@ def build_parser():
     p.add_argument("--arch", default="sparsedensenetrefinementmask")
     p.add_argument("--max_disp", type=int, default=216)
     p.add_argument("--base_channels", type=int, default=8)
-    p.add_argument("--cost_func", default="cor")
+    p.add_argument("--cost_func", default="ssd", help="ssd | cor | cat (demo.py:31; demo.sh and eval.sh pass cor)")
     p.add_argument("--grad_method", default="detach")
     p.add_argument("--num_stage", type=int, default=4)
     p.add_argument("--down_scale", type=int, default=3)

@@ -755,7 +755,7 @@ class SparseDenseNetRefinementMask(nn.Module):
         assert max_disp % down_scale ** (num_stage - 1) == 0, \
             "the max_disp({}) should be divisible by down_scale({})^num_stage({})".format(
                 max_disp, down_scale, num_stage)                      # reference :42
-        assert cost_func == "cor", "the MI355X path implements cost_func='cor' (demo.sh / eval.sh)"
+        assert cost_func in ("ssd", "cor", "cat"), "no such cost_func: {}".format(cost_func)     # submodule.py:447
         self.max_disp, self.num_stage, self.down_scale = max_disp, num_stage, down_scale
         self.skip_stage_id, self.use_detail, self.thold = skip_stage_id, use_detail, thold
         self.feature_extractor = FeatExtNetChannelPlus(base_channels, num_stage, down_scale)

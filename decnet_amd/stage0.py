@@ -77,26 +77,29 @@ def _to_ndhwc(x):
     return out
 
 
-def costvol_ndhwc(left, right, max_disp, out=None):
-    """[B,C,H,W] x2 -> channels-last cost volume [B,D,H,W,C] (cost_func="cor")."""
+def costvol_ndhwc(left, right, max_disp, out=None, cost_func="cor"):
+    """[B,C,H,W] x2 -> channels-last cost volume [B,D,H,W,C] ([B,D,H,W,2C] for cost_func="cat")."""
     _chk("left_feature_map", left)
     B, C, H, W = left.shape
     _chk("right_feature_map", right, (B, C, H, W))
     D = int(max_disp)
+    CO = 2 * C if cost_func == "cat" else C
     if out is None:
-        out = torch.empty((B, D, H, W, C), dtype=torch.float32, device=left.device)
+        out = torch.empty((B, D, H, W, CO), dtype=torch.float32, device=left.device)
     with torch.cuda.device(left.device):
-        rc = _lib.lib().decnet_costvol_forward(left.data_ptr(), right.data_ptr(), out.data_ptr(),
-                                               B, C, H, W, D, _stream(left))
-    _lib.check(rc, "decnet_costvol_forward")
+        rc = _lib.lib().decnet_costvol_forward_cf(left.data_ptr(), right.data_ptr(), out.data_ptr(),
+                                                  B, C, H, W, D, _lib.COST_FUNC[cost_func], _stream(left))
+    _lib.check(rc, "decnet_costvol_forward_cf")
     return out
 
 
 class GetCostVolume(nn.Module):
     """forward: compute the cost volume with warped features  (submodule.py:428-562)
 
-    Only the configuration the shipped network uses is implemented on the GPU:
-    warp_ope="homgrp", cost_func="cor", disp_samples = get_disp_samples(stage 0).
+    warp_ope="homgrp" with disp_samples = get_disp_samples(stage 0) -- the one call site of the reference
+    (SparseDenseNetRefinementMask.py:66, 131) -- and every cost_func: "cor" (demo.sh / eval.sh), "ssd" (demo.py:31's
+    default), "cat" (2C channels).  warp_ope="shift" cannot run in the reference either (submodule.py:463 names an
+    undefined variable) and is refused.
     return: cost volume, N*C*S*H*W (a view of the channels-last buffer)."""
 
     def __init__(self, warp_ope="homgrp", cost_func="ssd"):
@@ -106,9 +109,9 @@ class GetCostVolume(nn.Module):
         self.cost_func = cost_func
 
     def forward(self, left_feature_map, right_feature_map, **kargs):
-        if self.warp_ope != "homgrp" or self.cost_func != "cor":
-            raise NotImplementedError("the gfx950 path implements warp_ope='homgrp', "
-                                      "cost_func='cor' (demo.sh / eval.sh)")
+        if self.warp_ope != "homgrp":
+            raise NotImplementedError("the gfx950 path implements warp_ope='homgrp' (the reference's 'shift' raises "
+                                      "NameError, submodule.py:463)")
         if "disp_samples" in kargs and kargs["disp_samples"] is not None:
             ds = kargs["disp_samples"]
             D = int(ds.size(1))
@@ -121,7 +124,7 @@ class GetCostVolume(nn.Module):
                                           "arange(max_disp) only (submodule.py:389-390)")
         else:
             D = int(kargs["max_disp"])
-        cv = costvol_ndhwc(left_feature_map.contiguous(), right_feature_map.contiguous(), D)
+        cv = costvol_ndhwc(left_feature_map.contiguous(), right_feature_map.contiguous(), D, cost_func=self.cost_func)
         return cv.permute(0, 4, 1, 2, 3)
 
 
@@ -149,10 +152,10 @@ class CostRegNetNoDown(nn.Module):
 
     def __init__(self, in_channels, base_channels, cost_func, down_scale=3):
         super(CostRegNetNoDown, self).__init__()
-        if cost_func == "cat":
-            raise NotImplementedError("cost_func='cat' (conv_pre) is not used by the shipped net")
         self.cost_func = cost_func
         C = in_channels
+        if self.cost_func == "cat":                      # submodule.py:618-619
+            self.conv_pre = nn.Conv3d(C * 2, C, 1, stride=1, padding=0, bias=False)
         self.conv0 = nn.Sequential(Conv3dUnit(C, C, padding=1), Conv3dUnit(C, C, padding=1))
         self.conv1 = nn.Sequential(Conv3dUnit(C, C, padding=1), Conv3dUnit(C, C, padding=1),
                                    Conv3dUnit(C, C, padding=1))
@@ -175,7 +178,7 @@ class CostRegNetNoDown(nn.Module):
 
     # ---- parameter preparation (once per weight version): repack + BN folding -----------
     def _key(self):
-        k = []
+        k = [(self.conv_pre.weight.data_ptr(), self.conv_pre.weight._version)] if self.cost_func == "cat" else []
         for u in self.units():
             for t in (u.conv.weight, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var):
                 k.append((t.data_ptr(), t._version))
@@ -238,6 +241,19 @@ class CostRegNetNoDown(nn.Module):
                     assert Co == 1
                     packed.append(dict(w=w, scale=float(scale.item()), shift=float(shift.item()),
                                        Ci=Ci, Co=1, relu=0))
+            if self.cost_func == "cat":
+                # conv_pre.weight [C,2C,1,1,1] as [Cp][2 Cp] for the zero-padded feature maps of stage0() (left half in
+                # columns [0, C), right half in [Cp, Cp + C)), and as it is for a 2C-channel volume (forward())
+                wpre = self.conv_pre.weight.detach().float().reshape(self.conv_pre.weight.shape[0], -1).contiguous()
+                C = int(wpre.shape[0])
+                cp = (C + 3) & ~3
+                if cp != C:
+                    wp = torch.zeros((cp, 2 * cp), dtype=torch.float32, device=dev)
+                    wp[:C, :C] = wpre[:, :C]
+                    wp[:C, cp:cp + C] = wpre[:, C:]
+                else:
+                    wp = wpre
+                packed[0]["w_pre"], packed[0]["w_pre_true"] = wp, wpre
         self._packed, self._packed_key = packed, key
         return packed
 
@@ -266,6 +282,15 @@ class CostRegNetNoDown(nn.Module):
         algo = conv_algo(D)
         P = self.prepare(D)
         c_true = int(self.units()[0].conv.weight.shape[1])
+        if self.cost_func == "cat":                      # submodule.py:651-652: x = conv_pre(x), 2C -> C channels
+            if C != 2 * c_true:
+                raise ValueError("cost volume has %d channels, module expects %d" % (C, 2 * c_true))
+            y = torch.empty((B, D, H, W, c_true), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = _lib.lib().decnet_conv3d_pointwise(x.data_ptr(), P[0]["w_pre_true"].data_ptr(), y.data_ptr(), B, C,
+                                                        c_true, D * H * W, C, 1, _stream(x))
+            _lib.check(rc, "decnet_conv3d_pointwise")
+            x, C = y, c_true
         if C == c_true and P[0]["Ci"] != C:             # channel count not a multiple of 4: zero pad
             x = torch.nn.functional.pad(x, (0, P[0]["Ci"] - C))
             C = P[0]["Ci"]
@@ -369,8 +394,8 @@ class CostRegNetNoDown(nn.Module):
 
     def stage0(self, left_feature_map, right_feature_map, max_disp, return_reg=False):
         """SparseDenseNetRefinementMask.forward :127-137 in one call: cost volume (stage-0 ``arange``
-        samples) -> this regulariser -> soft-argmax, through the single C entry ``decnet_stage0_forward``
-        (one workspace, one ctypes call).  [B,C,H,W] x2 -> pred [B,H,W] (, reg [B,D,H,W])."""
+        samples) -> this regulariser -> soft-argmax, through the single C entry ``decnet_stage0_forward_cf``
+        (one workspace, one ctypes call; the module's cost_func picks the volume).  [B,C,H,W] x2 -> pred [B,H,W] (, reg [B,D,H,W])."""
         if self.training or (torch.is_grad_enabled() and (left_feature_map.requires_grad or
                                                           right_feature_map.requires_grad)):
             raise NotImplementedError("CostRegNetNoDown on gfx950 is inference-only: call "
@@ -407,9 +432,10 @@ class CostRegNetNoDown(nn.Module):
             sp.w_last, sp.scale_last, sp.shift_last = P[7]["w"].data_ptr(), P[7]["scale"], P[7]["shift"]
             pk = (P, variant, sp)
             self._ws[("s0params", dev)] = pk
-        n = L.decnet_stage0_workspace_floats(B, C, H, W, D, variant)
+        cf = _lib.COST_FUNC[self.cost_func]
+        n = L.decnet_stage0_cf_workspace_floats(B, C, H, W, D, variant, cf)
         if n == 0:
-            raise _lib.DecnetHipError("decnet_stage0_forward: shape not supported")
+            raise _lib.DecnetHipError("decnet_stage0_forward_cf: shape not supported")
         ws = self._ws.get(("s0", dev))
         if ws is None or ws.numel() < n:
             ws = torch.empty(n, dtype=torch.float32, device=dev)
@@ -418,10 +444,11 @@ class CostRegNetNoDown(nn.Module):
         pred = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         import ctypes
         with torch.cuda.device(dev):
-            rc = L.decnet_stage0_forward(left.data_ptr(), right.data_ptr(), ctypes.byref(pk[2]), ws.data_ptr(),
-                                         reg.data_ptr() if reg is not None else None, pred.data_ptr(),
-                                         B, C, H, W, D, variant, _stream(left))
-        _lib.check(rc, "decnet_stage0_forward")
+            rc = L.decnet_stage0_forward_cf(left.data_ptr(), right.data_ptr(), ctypes.byref(pk[2]),
+                                            P[0]["w_pre"].data_ptr() if self.cost_func == "cat" else None, ws.data_ptr(),
+                                            reg.data_ptr() if reg is not None else None, pred.data_ptr(),
+                                            B, C, H, W, D, variant, cf, _stream(left))
+        _lib.check(rc, "decnet_stage0_forward_cf")
         return (pred, reg) if return_reg else pred
 
     def stage0_buffers(self, dev, B, C, H, W, D):

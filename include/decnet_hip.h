@@ -118,6 +118,26 @@ int decnet_spamatvar_forward_bits(const float *ref, const float *tar, const unsi
  *   left,right [B,C,H,W];  cost_ndhwc [B,D,H,W,C].                                         */
 int decnet_costvol_forward(const float *left, const float *right, float *cost_ndhwc, int B,
                            int C, int H, int W, int D, void *stream);
+/* The other cost functions of GetCostVolume (submodule.py:511-530, chosen by --cost_func, demo.py:31 / eval.py:43), with
+ * l = (x >= d ? left[b,c,y,x] : 0) and r = bilinear(right[b,c]; ...) as above:
+ *   DECNET_COST_COR  l * r                               (:518-522; what decnet_costvol_forward computes)
+ *   DECNET_COST_SSD  (l^2 + r^2) / 2 - ((l + r) / 2)^2   (:524-530, the same fp32 operation sequence)
+ *   DECNET_COST_CAT  cost[..., c] = l, cost[..., C + c] = r: cost_ndhwc is [B,D,H,W,2C]   (:512-516)
+ *   DECNET_COST_SUM  l + r -- not a reference function: CostRegNetNoDown.conv_pre (the 1x1x1 convolution behind the
+ *                    "cat" volume, :618-619) is linear, so conv_pre(cat(l_vol, r_vol)) is the SUM volume of the two
+ *                    feature maps after each went through its half of conv_pre (decnet_stage0_forward_cf does that). */
+#define DECNET_COST_COR 0
+#define DECNET_COST_SSD 1
+#define DECNET_COST_CAT 2
+#define DECNET_COST_SUM 3
+int decnet_costvol_forward_cf(const float *left, const float *right, float *cost_ndhwc, int B,
+                              int C, int H, int W, int D, int cost_func, void *stream);
+/* Conv3d with kernel 1, stride 1, no bias (CostRegNetNoDown.conv_pre, submodule.py:618-619, 651-652):
+ *   y[b,co,p] = sum_ci w[co*ldw + ci] * x[b,ci,p],  p < P positions per sample, one fp32 fma chain in channel order;
+ *   channels_last = 0: x [B,Ci,P], y [B,Co,P] (NCHW / NCDHW);  1: x [B,P,Ci], y [B,P,Co] (the NDHWC volumes above).
+ *   ldw >= Ci: row pitch of w (2C when one half of conv_pre.weight [C,2C,1,1,1] is applied to one feature map). */
+int decnet_conv3d_pointwise(const float *x, const float *w, float *y, int B, int Ci, int Co, int P, int ldw,
+                            int channels_last, void *stream);
 
 /* Repack one Conv3d weight  [Co,Ci,3,3,3] (torch layout, submodule.py:109) into the kernels'
  * [27, Ci, CoP] layout, CoP = decnet_conv3d_packed_cout(Co), zero padded.                  */
@@ -179,6 +199,11 @@ int decnet_costvol_wino_stack_bn_act(const float *left, const float *right, cons
                                      const float *const *scale, const float *const *shift, int n_layers, int res_src,
                                      int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
                                      int variant, void *stream);
+/* ... with the cost function DECNET_COST_COR / _SSD / _SUM (DECNET_ERR_BAD_SHAPE for _CAT: see decnet_stage0_forward_cf). */
+int decnet_costvol_wino_stack_bn_act_cf(const float *left, const float *right, const float *const *u,
+                                        const float *const *scale, const float *const *shift, int n_layers, int res_src,
+                                        int res_dst, float *y, float *workspace, int B, int C, int H, int W, int D,
+                                        int variant, int cost_func, void *stream);
 /* Last Conv3dUnit (Ci -> 1, BN, no ReLU; submodule.py:641) fused with disparity_regression
  * over disp_samples = arange(D) (submodule.py:766-777):
  *   reg[b,d,y,x]  = conv(x)[b,d,y,x] * scale + shift        (optional output, may be NULL)
@@ -222,6 +247,16 @@ size_t decnet_stage0_workspace_floats(int B, int C, int H, int W, int D, int var
 int decnet_stage0_forward(const float *left, const float *right, const decnet_stage0_params *params,
                           float *workspace, float *reg, float *pred, int B, int C, int H, int W, int D,
                           int variant, void *stream);
+/* The same branch for every --cost_func of the reference (submodule.py:552-560): cost_func = DECNET_COST_COR, _SSD or
+ * _CAT.  w_pre: CostRegNetNoDown.conv_pre.weight [C,2C,1,1,1] (torch layout) for _CAT, ignored (may be NULL) otherwise.
+ * _CAT never forms the 2C-channel volume: conv_pre is applied to the two feature maps (its left half to `left`, its right
+ * half to `right`: two [C x C] products over B*H*W pixels instead of one [C x 2C] over B*D*H*W voxels -- bilinear warping
+ * and the left mask commute with a per-pixel linear map) and the stack runs on their DECNET_COST_SUM volume.
+ * Workspace: decnet_stage0_cf_workspace_floats floats. */
+size_t decnet_stage0_cf_workspace_floats(int B, int C, int H, int W, int D, int variant, int cost_func);
+int decnet_stage0_forward_cf(const float *left, const float *right, const decnet_stage0_params *params,
+                             const float *w_pre, float *workspace, float *reg, float *pred, int B, int C, int H, int W,
+                             int D, int variant, int cost_func, void *stream);
 
 /* disparity_regression for arbitrary samples (submodule.py:766-777):
  *   cost, samples [B,S,H,W] -> pred [B,H,W]                                                */

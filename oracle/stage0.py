@@ -5,6 +5,8 @@ torch-CPU restatement of the reference's stage-0 dense path (coarsest level):
   get_disp_samples (stage-0 branch)       modules/submodule.py:389-390
   GetCostVolume.get_warped_feats_by_homgrp modules/submodule.py:479-510
   GetCostVolume.cost_computation_cor       modules/submodule.py:518-522
+  GetCostVolume.cost_computation_cat / ssd modules/submodule.py:512-516, 524-530
+  CostRegNetNoDown.conv_pre (cost_func cat) modules/submodule.py:618-619, 651-652
   Conv3dUnit / CostRegNetNoDown.forward    modules/submodule.py:90-123, 608-662
   disparity_regression                     modules/submodule.py:766-777
 
@@ -90,9 +92,9 @@ def warp_right_closed_form(right, max_disp):
     return torch.from_numpy(out)
 
 
-def cost_volume(left, right, max_disp):
-    """GetCostVolume(warp_ope="homgrp", cost_func="cor").forward -> [B,C,D,H,W]
-    (submodule.py:532-562 with :505-509 left masking and :521 product)."""
+def cost_volume(left, right, max_disp, cost_func="cor"):
+    """GetCostVolume(warp_ope="homgrp", cost_func=...).forward -> [B,C,D,H,W] ([B,2C,D,H,W] for "cat")
+    (submodule.py:532-562 with :505-509 left masking; :521 product, :514 concatenation, :527-529 ssd)."""
     B, C, H, W = left.shape
     samples = disp_samples(max_disp, B, H, W, left.dtype)
     right_vol = warp_right(right, samples)
@@ -100,7 +102,15 @@ def cost_volume(left, right, max_disp):
     pos_x = torch.arange(W, dtype=left.dtype).view(1, 1, 1, W).expand(B, samples.shape[1], H, W)
     keep = ~(pos_x < samples)                                            # x >= d
     left_vol = left_vol * keep.unsqueeze(1).to(left.dtype)
-    return left_vol * right_vol
+    if cost_func == "cor":
+        return left_vol * right_vol
+    if cost_func == "cat":
+        return torch.cat((left_vol, right_vol), dim=1)
+    if cost_func == "ssd":                                               # the reference's in-place sequence, out of place
+        volume_sum = left_vol + right_vol
+        volume_sqr = left_vol.pow(2) + right_vol.pow(2)
+        return volume_sqr.div(2).sub(volume_sum.div(2).pow(2))
+    raise ValueError("No such cost computation function: {}".format(cost_func))
 
 
 def conv3d_unit(x, w, bn, relu):
@@ -112,10 +122,13 @@ def conv3d_unit(x, w, bn, relu):
     return F.relu(x) if relu else x
 
 
-def cost_regularizer(x, params):
-    """CostRegNetNoDown.forward (submodule.py:650-662), cost_func="cor".
+def cost_regularizer(x, params, w_pre=None):
+    """CostRegNetNoDown.forward (submodule.py:650-662).
     params: list of 8 dicts {"w": [Co,Ci,3,3,3], "bn": (gamma,beta,mean,var)} in module
-    order conv0[0..1], conv1[0..2], conv2[0..2].  -> [B,D,H,W]"""
+    order conv0[0..1], conv1[0..2], conv2[0..2];  w_pre: conv_pre.weight [C,2C,1,1,1] of cost_func="cat"
+    (:618-619, applied first :651-652), else None.  -> [B,D,H,W]"""
+    if w_pre is not None:
+        x = F.conv3d(x, w_pre, None, stride=1, padding=0)
     u = lambda i, t, relu=True: conv3d_unit(t, params[i]["w"], params[i]["bn"], relu)
     o0 = u(1, u(0, x))
     o = u(4, u(3, u(2, o0))) + o0
@@ -128,11 +141,12 @@ def disparity_regression(cost, samples):
     return torch.sum(F.softmax(cost, dim=1) * samples, 1)
 
 
-def stage0_forward(left, right, params, max_disp):
+def stage0_forward(left, right, params, max_disp, cost_func="cor", w_pre=None):
     """The whole stage-0 branch of SparseDenseNetRefinementMask.forward (:127-137)."""
     B, C, H, W = left.shape
-    cv = cost_volume(left, right, max_disp)
-    reg = cost_regularizer(cv, params)
+    assert (w_pre is not None) == (cost_func == "cat")
+    cv = cost_volume(left, right, max_disp, cost_func)
+    reg = cost_regularizer(cv, params, w_pre)
     return disparity_regression(reg, disp_samples(max_disp, B, H, W, left.dtype)), reg, cv
 
 
@@ -165,3 +179,9 @@ def random_params(C, seed, bn_random=True):
             bn = (torch.ones(co), torch.zeros(co), torch.zeros(co), torch.ones(co))
         out.append({"w": w, "bn": bn})
     return out
+
+
+def random_w_pre(C, seed):
+    """Deterministic conv_pre.weight [C,2C,1,1,1] of cost_func="cat" (init as :246-248: N(0, sqrt(2 / C)))."""
+    g = torch.Generator().manual_seed(int(seed) + 4242)
+    return torch.randn(C, 2 * C, 1, 1, 1, generator=g) * float(np.sqrt(2.0 / C))

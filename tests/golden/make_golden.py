@@ -97,14 +97,19 @@ def flat_params(params):
     return d
 
 
-def stage0_case(sub, C, B, H, W, D, seed, store_params):
+def stage0_case(sub, C, B, H, W, D, seed, store_params, cost_func="cor"):
     torch.manual_seed(seed)
     left = torch.relu(torch.randn(B, C, H, W))
     right = torch.relu(torch.randn(B, C, H, W))
-    gcv = sub.GetCostVolume(warp_ope="homgrp", cost_func="cor")
-    reg = sub.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func="cor", down_scale=3)
+    gcv = sub.GetCostVolume(warp_ope="homgrp", cost_func=cost_func)
+    reg = sub.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func=cost_func, down_scale=3)
     params = o0.random_params(C, seed + 1000)
     load_params(reg, params)
+    w_pre = None
+    if cost_func == "cat":                             # submodule.py:618-619
+        w_pre = o0.random_w_pre(C, seed + 1000)
+        assert tuple(reg.conv_pre.weight.shape) == tuple(w_pre.shape)
+        reg.conv_pre.weight.data = w_pre.clone()
     reg.eval()
     with torch.no_grad():
         ds = sub.get_disp_samples(D, left, stage_id=0)
@@ -117,6 +122,10 @@ def stage0_case(sub, C, B, H, W, D, seed, store_params):
                w7_checksum=np.float64(params[7]["w"].double().abs().sum().item()))
     if store_params:
         out.update(flat_params(params))
+    if w_pre is not None:
+        out["w_pre_checksum"] = np.float64(w_pre.double().abs().sum().item())
+        if store_params:
+            out["w_pre"] = w_pre.numpy()
     return out
 
 
@@ -182,13 +191,13 @@ def e2e_inputs(seed=99, H=54, W=243):
     return torch.randn(1, 3, H, W, generator=g), torch.randn(1, 3, H, W, generator=g)
 
 
-def e2e_case():
+def e2e_case(cost_func="cor"):
     """Whole reference graph (base_channels=2 so that the run is small) with seeded synthetic
     parameters (tests/golden/netparams.py -- regenerated by the test, not stored): the network's
     final disparity and the per-stage sparse results.  SpaMat/SpaVar are the oracle stub."""
     from modules import get_model
     from netparams import fill_state_dict
-    model = get_model(**E2E_KW)
+    model = get_model(**dict(E2E_KW, cost_func=cost_func))
     model.load_state_dict(fill_state_dict(model.state_dict()))
     model.eval()
     rec = {}
@@ -216,16 +225,18 @@ def full_inputs(B, C, H, W, seed):
     return left, right
 
 
-def stage0_full_case(sub, C, B, H, W, D, seed):
+def stage0_full_case(sub, C, B, H, W, D, seed, cost_func="cor"):
     """BASELINE config 2's full stage-0 shape (216 channels, 20 x 36, D = 8) through the REFERENCE's classes; every op is
     per sample; B = 8 is the whole batch of the bench step.  Outputs only (the cost volume alone would be 40 MB)."""
     import zlib
     ln, rn = full_inputs(B, C, H, W, seed)
     left, right = torch.from_numpy(ln), torch.from_numpy(rn)
-    gcv = sub.GetCostVolume(warp_ope="homgrp", cost_func="cor")
-    reg = sub.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func="cor", down_scale=3)
+    gcv = sub.GetCostVolume(warp_ope="homgrp", cost_func=cost_func)
+    reg = sub.CostRegNetNoDown(in_channels=C, base_channels=2 * C, cost_func=cost_func, down_scale=3)
     params = o0.random_params(C, seed + 1000)
     load_params(reg, params)
+    if cost_func == "cat":
+        reg.conv_pre.weight.data = o0.random_w_pre(C, seed + 1000)
     reg.eval()
     with torch.no_grad():
         ds = sub.get_disp_samples(D, left, stage_id=0)
@@ -242,6 +253,18 @@ def stage0_full_case(sub, C, B, H, W, D, seed):
 def main():
     install_stubs()
     import modules.submodule as sub
+    if "--only-costfunc" in sys.argv:
+        # cost_func "ssd" (demo.py:31's default) and "cat" (+ CostRegNetNoDown.conv_pre): the reference's own classes again
+        for cf in ("ssd", "cat"):
+            np.savez_compressed(os.path.join(HERE, "stage0_%s_small.npz" % cf),
+                                **stage0_case(sub, C=12, B=2, H=5, W=9, D=4, seed=5, store_params=True, cost_func=cf))
+            np.savez_compressed(os.path.join(HERE, "stage0_%s_c216.npz" % cf),
+                                **stage0_case(sub, C=216, B=1, H=4, W=7, D=8, seed=7, store_params=False, cost_func=cf))
+            np.savez_compressed(os.path.join(HERE, "stage0_cfg2_%s_full.npz" % cf),
+                                **stage0_full_case(sub, C=216, B=8, H=20, W=36, D=8, seed=11, cost_func=cf))
+            sys.path.insert(0, HERE)                   # the whole graph with the other stage-0 volume
+            np.savez_compressed(os.path.join(HERE, "e2e_bc2_54x243_%s.npz" % cf), **e2e_case(cf))
+        return
     if "--only-stage0-full" in sys.argv:               # (minutes of CPU: 203 GFLOP through torch's Conv3d)
         np.savez_compressed(os.path.join(HERE, "stage0_cfg2_full.npz"),
                             **stage0_full_case(sub, C=216, B=8, H=20, W=36, D=8, seed=11))

@@ -65,6 +65,9 @@ def test_bench_line_contract():
     alt = d["alt_wino_gemm_fp32"]                      # round 2's fp32 MFMA Winograd GEMM, measured in a child process
     assert "error" not in alt, alt
     assert alt["value"] > 0 and alt["wino_gemm_ms"] > 0 and 0 < alt["fp32_mfma_frac"] < 1.0
+    cfs = d["stage0_cost_funcs"]                       # the stage-0 branch with each --cost_func of the reference
+    assert "error" not in cfs, cfs
+    assert 0 < cfs["cor_ms"] and 0.7 < cfs["ssd_ms"] / cfs["cor_ms"] < 1.5 and 0.7 < cfs["cat_ms"] / cfs["cor_ms"] < 1.5
 
 
 def test_costvol_density_map_and_e2e_objects():

@@ -21,14 +21,18 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 
 
-def test_e2e_against_reference_graph():
+@pytest.mark.parametrize("cost_func", ["cor", "ssd", "cat"])
+def test_e2e_against_reference_graph(cost_func):
+    """cost_func: demo.sh / eval.sh pass "cor"; demo.py:31's own default is "ssd"; "cat" adds CostRegNetNoDown.conv_pre
+    (a key of the checkpoint).  Goldens: make_golden.py (cor) / make_golden.py --only-costfunc."""
     assert torch.cuda.is_available()
     from netparams import fill_state_dict
     from make_golden import E2E_KW, e2e_inputs
     from decnet_amd.model import get_model, load_reference_checkpoint
-    d = np.load(os.path.join(HERE, "golden", "e2e_bc2_54x243.npz"))
+    d = np.load(os.path.join(HERE, "golden", "e2e_bc2_54x243%s.npz" % ("" if cost_func == "cor" else "_" + cost_func)))
     dev = torch.device("cuda:0")
-    model = get_model(**E2E_KW)
+    model = get_model(**dict(E2E_KW, cost_func=cost_func))
+    assert ("cost_regularizer.conv_pre.weight" in model.state_dict()) == (cost_func == "cat")
     sd = fill_state_dict(model.state_dict())
     assert abs(sum(v.double().abs().sum().item() for v in sd.values()) - float(d["w_checksum"])) < 1e-6
     load_reference_checkpoint(model, {"module." + k: v for k, v in sd.items()})   # DataParallel prefix

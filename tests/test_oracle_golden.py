@@ -75,6 +75,40 @@ def test_stage0_full_size_golden_pins_the_oracle(golden_dir):
     np.testing.assert_allclose(pred.numpy(), d["pred"][5:7], rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("cf", ["ssd", "cat"])
+def test_stage0_other_cost_functions_match_reference(golden_dir, cf):
+    """cost_func "ssd" (submodule.py:524-530; demo.py:31's default) and "cat" (:512-516 + CostRegNetNoDown.conv_pre
+    :618-619, 651-652) through the REFERENCE's classes (make_golden.py --only-costfunc): small case with stored
+    parameters, 216-channel case and two samples of config 2's full batch with seeded ones."""
+    d = _load(golden_dir, "stage0_%s_small.npz" % cf)
+    left, right = torch.from_numpy(d["left"]), torch.from_numpy(d["right"])
+    w_pre = torch.from_numpy(d["w_pre"]) if cf == "cat" else None
+    pred, reg, cv = o0.stage0_forward(left, right, _params_from_npz(d), int(d["max_disp"]), cf, w_pre)
+    assert cv.shape[1] == (2 if cf == "cat" else 1) * left.shape[1]
+    np.testing.assert_allclose(cv.numpy(), d["cost_vol"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(reg.numpy(), d["reg"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(pred.numpy(), d["pred"], rtol=0, atol=2e-5)
+    for name, sl in (("stage0_%s_c216.npz" % cf, None), ("stage0_cfg2_%s_full.npz" % cf, slice(2, 4))):
+        d = _load(golden_dir, name)
+        seed = int(d["param_seed"])
+        params = o0.random_params(216, seed)
+        assert abs(params[0]["w"].double().sum().item() - float(d["w0_checksum"])) < 1e-9
+        w_pre = o0.random_w_pre(216, seed) if cf == "cat" else None
+        if w_pre is not None and "w_pre_checksum" in d.files:
+            assert abs(w_pre.double().abs().sum().item() - float(d["w_pre_checksum"])) < 1e-9
+        if sl is None:
+            left, right = torch.from_numpy(d["left"]), torch.from_numpy(d["right"])
+            want_reg, want_pred = d["reg"], d["pred"]
+        else:
+            left, right = (t[sl] for t in full_case_inputs(d))
+            want_reg, want_pred = d["reg"][sl], d["pred"][sl]
+        pred, reg, cv = o0.stage0_forward(left, right, params, int(d["max_disp"]), cf, w_pre)
+        if sl is None:
+            np.testing.assert_allclose(cv.numpy(), d["cost_vol"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(reg.numpy(), want_reg, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want_reg).max())))
+        np.testing.assert_allclose(pred.numpy(), want_pred, rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("name", ["stage0_small.npz", "stage0_c216.npz"])
 def test_closed_form_warp_equals_grid_sample(golden_dir, name):
     """the stretched, half-pixel-shifted bilinear warp in closed form."""
