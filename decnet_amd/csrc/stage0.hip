@@ -120,66 +120,106 @@ __global__ __launch_bounds__(512) void costvol_ndhwc(const float *__restrict__ l
 // ----------------------------- Conv3d kernel 1 (conv_pre) ------------------------------
 // y[b, co, p] = sum_ci w[co][ci] x[b, ci, p]   (CL = false: x [B][Ci][P], y [B][Co][P]; CL = true: x [B][P][Ci],
 // y [B][P][Co]): CostRegNetNoDown.conv_pre of cost_func "cat" (submodule.py:618-619: Conv3d(2 C, C, 1), no bias).  A
-// workgroup owns PW_TP positions: their Ci inputs in LDS, the weights through LDS in chunks of 32 input channels
-// (transposed, so that a lane's read is its own output channel), thread = output channel, PW_TP accumulators; the
-// sum over ci is one fp32 fma chain in channel order.
-constexpr int PW_TP = 32, PW_CK = 32, PW_THREADS = 256;
+// workgroup owns PW_TP = 32 positions: their Ci inputs in LDS, the weights through LDS in chunks of 32 input channels
+// (transposed: [k][co]).  Wave = 8 of the positions, lane = 4 consecutive output channels (256 per pass): per input
+// channel one 16-byte LDS read of the lane's four weights and two wave-uniform 16-byte reads of the eight inputs feed 32
+// fmas (thread = one output channel x 32 positions needed nine reads per 32 fmas and was LDS bound: 48 us against 26 at
+// B = 8, C = 216, 20 x 36).  The sum over ci is one fp32 fma chain in channel order.
+constexpr int PW_TP = 32, PW_CK = 32, PW_THREADS = 256, PW_WP = PW_THREADS + 4;   // pitch: 16-byte rows, == 4 (mod 32)
+// blockIdx.z = 1: the second problem of the same shape (x2, w2, y2): the two halves of conv_pre on the two feature maps
+// as one launch (each alone is 184 workgroups on 256 CUs at config 2).
 template <bool CL>
 __global__ __launch_bounds__(PW_THREADS) void pointwise_conv(const float *__restrict__ x, const float *__restrict__ w,
-                                                            float *__restrict__ y, int Ci, int Co, int P, int ldw) {
+                                                            float *__restrict__ y, const float *__restrict__ x2,
+                                                            const float *__restrict__ w2, float *__restrict__ y2, int Ci,
+                                                            int Co, int P, int ldw) {
+    if (blockIdx.z) {
+        x = x2;
+        w = w2;
+        y = y2;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Xs = smem;                              // [Ci][PW_TP]
-    const int WP = min(Co, PW_THREADS) | 1;
-    float *Ws = smem + (size_t)Ci * PW_TP;          // [PW_CK][WP]
+    float *Ws = smem + (size_t)Ci * PW_TP;          // [PW_CK][PW_WP]
     const int b = blockIdx.y, p0 = blockIdx.x * PW_TP, np = min(PW_TP, P - p0);
     const float *xb = x + (size_t)b * Ci * P;
     float *yb = y + (size_t)b * Co * P;
-    if (CL) {
-        for (int i = threadIdx.x; i < Ci * PW_TP; i += PW_THREADS) {
-            const int pp = i / Ci, ci = i - pp * Ci;                     // consecutive lanes: consecutive channels
-            Xs[ci * PW_TP + pp] = pp < np ? xb[(size_t)(p0 + pp) * Ci + ci] : 0.f;
+    // (loads in batches of eight / thirty-two per thread, all in flight together: with one workgroup per CU a load per
+    // loop iteration is a chain of round trips -- 27 for the inputs, 27 per weight chunk -- and was 0.1 ms of a 0.11 ms launch)
+    for (int i0 = threadIdx.x; i0 < Ci * PW_TP; i0 += 8 * PW_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * PW_THREADS;
+            if (CL) {
+                const int pp = i / Ci, ci = i - pp * Ci;                 // consecutive lanes: consecutive channels
+                v[u] = i < Ci * PW_TP && pp < np ? xb[(size_t)(p0 + pp) * Ci + ci] : 0.f;
+            } else {
+                const int ci = i / PW_TP, pp = i - ci * PW_TP;           // consecutive lanes: consecutive positions
+                v[u] = i < Ci * PW_TP && pp < np ? xb[(size_t)ci * P + p0 + pp] : 0.f;
+            }
         }
-    } else {
-        for (int i = threadIdx.x; i < Ci * PW_TP; i += PW_THREADS) {
-            const int ci = i / PW_TP, pp = i - ci * PW_TP;               // consecutive lanes: consecutive positions
-            Xs[i] = pp < np ? xb[(size_t)ci * P + p0 + pp] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * PW_THREADS;
+            if (i < Ci * PW_TP) {
+                if (CL) {
+                    const int pp = i / Ci, ci = i - pp * Ci;
+                    Xs[ci * PW_TP + pp] = v[u];
+                } else {
+                    Xs[i] = v[u];
+                }
+            }
         }
     }
+    constexpr int WU = PW_CK;                                             // weight elements per thread and chunk
+    const int wk = threadIdx.x & (PW_CK - 1), wr0 = threadIdx.x / PW_CK;  // 32 consecutive input channels of one row
+    const int cg = threadIdx.x & 63, pg = threadIdx.x >> 6;               // output channels 4 cg .. 4 cg + 3, positions 8 pg ..
     for (int co0 = 0; co0 < Co; co0 += PW_THREADS) {
-        const int co = co0 + threadIdx.x;
-        float acc[PW_TP];
+        const int rows = min(PW_THREADS, Co - co0);
+        float acc[4][8], wreg[WU];
 #pragma unroll
-        for (int j = 0; j < PW_TP; ++j) acc[j] = 0.f;
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
+        auto load_w = [&](int c0) {
+#pragma unroll
+            for (int u = 0; u < WU; ++u) {
+                const int r = wr0 + u * (PW_THREADS / PW_CK);
+                wreg[u] = r < rows && c0 + wk < Ci ? w[(size_t)(co0 + r) * ldw + c0 + wk] : 0.f;
+            }
+        };
+        load_w(0);
         for (int c0 = 0; c0 < Ci; c0 += PW_CK) {
             __syncthreads();                                             // Xs written / the previous chunk's Ws read
-            for (int i = threadIdx.x; i < PW_CK * min(PW_THREADS, Co - co0); i += PW_THREADS) {
-                const int r = i / PW_CK, k = i - r * PW_CK;              // 32 consecutive input channels of one row
-                Ws[k * WP + r] = c0 + k < Ci ? w[(size_t)(co0 + r) * ldw + c0 + k] : 0.f;
-            }
-            __syncthreads();
-            if (co < Co) {
-                const int kn = min(PW_CK, Ci - c0);
-                for (int k = 0; k < kn; ++k) {
-                    const float wv = Ws[k * WP + threadIdx.x];
-                    const float4 *xr = reinterpret_cast<const float4 *>(Xs + (size_t)(c0 + k) * PW_TP);
 #pragma unroll
-                    for (int j = 0; j < PW_TP / 4; ++j) {
-                        const float4 v = xr[j];                          // the same address in every lane: broadcast
-                        acc[4 * j] = fmaf(wv, v.x, acc[4 * j]);
-                        acc[4 * j + 1] = fmaf(wv, v.y, acc[4 * j + 1]);
-                        acc[4 * j + 2] = fmaf(wv, v.z, acc[4 * j + 2]);
-                        acc[4 * j + 3] = fmaf(wv, v.w, acc[4 * j + 3]);
-                    }
-                }
+            for (int u = 0; u < WU; ++u) Ws[wk * PW_WP + wr0 + u * (PW_THREADS / PW_CK)] = wreg[u];   // zeros beyond `rows`
+            __syncthreads();
+            if (c0 + PW_CK < Ci) load_w(c0 + PW_CK);                     // in flight during this chunk's arithmetic
+            const int kn = min(PW_CK, Ci - c0);
+#pragma unroll 4
+            for (int k = 0; k < kn; ++k) {
+                const float4 wv = *reinterpret_cast<const float4 *>(Ws + k * PW_WP + 4 * cg);
+                const float4 *xr = reinterpret_cast<const float4 *>(Xs + (size_t)(c0 + k) * PW_TP + 8 * pg);
+                const float4 xa = xr[0], xc = xr[1];                     // the same address in every lane: broadcast
+                const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, xs[8] = {xa.x, xa.y, xa.z, xa.w, xc.x, xc.y, xc.z, xc.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[c][j] = fmaf(ws[c], xs[j], acc[c][j]);
             }
         }
-        if (co < Co) {
 #pragma unroll
-            for (int j = 0; j < PW_TP; ++j)
-                if (j < np) {
-                    if (CL) yb[(size_t)(p0 + j) * Co + co] = acc[j];
-                    else yb[(size_t)co * P + p0 + j] = acc[j];
-                }
+        for (int c = 0; c < 4; ++c) {
+            const int co = co0 + 4 * cg + c;
+            if (co < Co) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (8 * pg + j < np) {
+                        if (CL) yb[(size_t)(p0 + 8 * pg + j) * Co + co] = acc[c][j];
+                        else yb[(size_t)co * P + p0 + 8 * pg + j] = acc[c][j];
+                    }
+            }
         }
     }
 }
@@ -624,24 +664,38 @@ int decnet_costvol_forward_cf(const float *left, const float *right, float *cost
     return decnet_launch_status();
 }
 
-int decnet_conv3d_pointwise(const float *x, const float *w, float *y, int B, int Ci, int Co, int P, int ldw,
-                            int channels_last, void *stream) {
+static int pointwise_launch(const float *x, const float *w, float *y, const float *x2, const float *w2, float *y2, int B,
+                            int Ci, int Co, int P, int ldw, int channels_last, void *stream) {
     if (!x || !w || !y) return DECNET_ERR_NULL_POINTER;
     if (B < 1 || Ci < 1 || Co < 1 || P < 1 || ldw < Ci) return DECNET_ERR_BAD_SHAPE;
     if (B > 65535 || (double)P * (Ci > Co ? Ci : Co) >= 2147483648.0 * 2) return DECNET_ERR_BAD_SHAPE;
-    const size_t lds = ((size_t)Ci * PW_TP + (size_t)PW_CK * ((Co < PW_THREADS ? Co : PW_THREADS) | 1)) * 4;
+    const size_t lds = ((size_t)Ci * PW_TP + (size_t)PW_CK * PW_WP) * 4;
     if (lds > DECNET_LDS_BYTES - 1024) return DECNET_ERR_UNSUPPORTED;
     const void *fn = channels_last ? (const void *)pointwise_conv<true> : (const void *)pointwise_conv<false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const dim3 grid((unsigned)((P + PW_TP - 1) / PW_TP), (unsigned)B);
+    const dim3 grid((unsigned)((P + PW_TP - 1) / PW_TP), (unsigned)B, x2 ? 2u : 1u);
     if (channels_last)
-        hipLaunchKernelGGL(pointwise_conv<true>, grid, dim3(PW_THREADS), lds, (hipStream_t)stream, x, w, y, Ci, Co, P, ldw);
+        hipLaunchKernelGGL(pointwise_conv<true>, grid, dim3(PW_THREADS), lds, (hipStream_t)stream, x, w, y, x2, w2, y2, Ci, Co,
+                           P, ldw);
     else
-        hipLaunchKernelGGL(pointwise_conv<false>, grid, dim3(PW_THREADS), lds, (hipStream_t)stream, x, w, y, Ci, Co, P, ldw);
+        hipLaunchKernelGGL(pointwise_conv<false>, grid, dim3(PW_THREADS), lds, (hipStream_t)stream, x, w, y, x2, w2, y2, Ci, Co,
+                           P, ldw);
     return decnet_launch_status();
+}
+
+int decnet_conv3d_pointwise(const float *x, const float *w, float *y, int B, int Ci, int Co, int P, int ldw,
+                            int channels_last, void *stream) {
+    return pointwise_launch(x, w, y, nullptr, nullptr, nullptr, B, Ci, Co, P, ldw, channels_last, stream);
+}
+
+// two products of one shape in one launch (not in the public header: decnet_stage0_forward_cf's conv_pre halves)
+int decnet_conv3d_pointwise_pair(const float *x, const float *w, float *y, const float *x2, const float *w2, float *y2,
+                                 int B, int Ci, int Co, int P, int ldw, void *stream) {
+    if (!x2 || !w2 || !y2) return DECNET_ERR_NULL_POINTER;
+    return pointwise_launch(x, w, y, x2, w2, y2, B, Ci, Co, P, ldw, 0, stream);
 }
 
 int decnet_conv3d_packed_cout(int Co) { return Co >= 1 && Co <= CONV_BN ? CONV_BN : -1; }

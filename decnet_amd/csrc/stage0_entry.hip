@@ -15,6 +15,10 @@ inline int auto_variant(int D) { return 216 * ((D + 3) / 4) <= 0.92 * 144 * ((D 
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 }  // namespace
 
+// csrc/stage0.hip (library-internal)
+extern "C" int decnet_conv3d_pointwise_pair(const float *x, const float *w, float *y, const float *x2, const float *w2,
+                                            float *y2, int B, int Ci, int Co, int P, int ldw, void *stream);
+
 extern "C" {
 
 size_t decnet_stage0_cf_workspace_floats(int B, int C, int H, int W, int D, int variant, int cost_func) {
@@ -78,8 +82,7 @@ int decnet_stage0_forward_cf(const float *left, const float *right, const decnet
         if (H < 1 || W < 1 || (double)H * W >= 2147483648.0) return DECNET_ERR_BAD_SHAPE;
         const size_t fm = align64((size_t)B * C * H * W);
         float *pl = ws + wino + (last > act ? align64(last) : 0), *pr = pl + fm;
-        if ((rc = decnet_conv3d_pointwise(left, w_pre, pl, B, C, C, H * W, 2 * C, 0, stream))) return rc;
-        if ((rc = decnet_conv3d_pointwise(right, w_pre + C, pr, B, C, C, H * W, 2 * C, 0, stream))) return rc;
+        if ((rc = decnet_conv3d_pointwise_pair(left, w_pre, pl, right, w_pre + C, pr, B, C, C, H * W, 2 * C, stream))) return rc;
         left = pl;
         right = pr;
         cf = DECNET_COST_SUM;
