@@ -1,6 +1,6 @@
 """Random stage-0 shapes (B, C, H, W, D) and random CostRegNetNoDown weights: decnet_amd.Stage0 (cost volume + Winograd stack
-+ fused last layer / soft-argmax on the MI355X) against oracle/stage0.py (the CPU restatement of submodule.py:479-522,
-608-662, 766-777), the tolerances of tests/test_stage0_gpu.py::test_vs_oracle_seeded.
++ fused last layer / soft-argmax on the MI355X; cost_func cor / ssd / cat by seed) against oracle/stage0.py (the CPU restatement
+of submodule.py:479-530, 608-662, 766-777), the tolerances of tests/test_stage0_gpu.py::test_vs_oracle_seeded.
 python tools/fuzz_stage0.py [first_seed [n [seconds]]]"""
 import os
 import sys
@@ -33,14 +33,16 @@ for seed in range(first, first + n):
     D = int(rng.randint(2, 13))
     if C == 216:
         H, W = min(H, 14), min(W, 24)
-    tag = dict(seed=seed, B=B, C=C, H=H, W=W, D=D)
+    cf = ("cor", "ssd", "cat")[seed % 3]                        # every --cost_func of the reference (submodule.py:552-560)
+    tag = dict(seed=seed, B=B, C=C, H=H, W=W, D=D, cost_func=cf)
     g = torch.Generator().manual_seed(seed)
     left = torch.relu(torch.randn(B, C, H, W, generator=g))
     right = torch.relu(torch.randn(B, C, H, W, generator=g))
     params = o0.random_params(C, 1000 + seed)
+    w_pre = o0.random_w_pre(C, 1000 + seed) if cf == "cat" else None
     with torch.no_grad():
-        pred_o, reg_o, _ = o0.stage0_forward(left, right, params, D)
-        reg = t.load_reg(C, params, dev)
+        pred_o, reg_o, _ = o0.stage0_forward(left, right, params, D, cf, w_pre)
+        reg = t.load_reg(C, params, dev, cf, w_pre)
         try:
             pred, r = decnet_amd.Stage0(reg)(left.to(dev), right.to(dev), D, return_reg=True)
         except Exception as e:
