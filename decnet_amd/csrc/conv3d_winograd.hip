@@ -655,6 +655,9 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
 #endif
 }
 
+// pitch of the warped-row table of wino_head_transform: >= W + D - 1, == 8 (mod 32)
+__host__ __device__ inline int head_rw_pitch(int W, int D) { return ((W + D - 1 + 23) & ~31) + 8; }
+
 // ---- cost volume + input transform of the first layer (the cost volume never reaches HBM) ----
 // stage0.hip:costvol_cor_ndhwc computes cost[b,d,y,x,c] = (x >= d ? L[b,c,y,x] : 0) * bilinear(R[b,c]; x - d, y)
 // (GetCostVolume, submodule.py:479-522: warp_ope "homgrp", cost_func "cor") for decnet_costvol_forward; here the same
@@ -666,7 +669,7 @@ template <int CF>
 __global__ __launch_bounds__(MID_THREADS) void wino_head_transform(
     const float *__restrict__ left, const float *__restrict__ right, float *__restrict__ V, Tiling g, int C, int nt) {
 #pragma clang fp contract(off)
-    extern __shared__ float ys[];                       // [D][H][4][Wp] | L [4][H][W] | R [4][H][W] | tables
+    extern __shared__ float ys[];                       // [D][H][4][Wp] | L [4][H][W] | R [4][H][W] | tables | RW
     constexpr int O = 4;
     const int D = g.D, H = g.H, W = g.W, Wp = W | 1, vol = D * H * 4 * Wp, plane = H * W;
     const int nq = (C + 3) >> 2, Q = pad16(C) >> 2;
@@ -709,32 +712,41 @@ __global__ __launch_bounds__(MID_THREADS) void wino_head_transform(
         ty[3 * y] = fy; ty[3 * y + 2] = iy - fy; ty[3 * y + 1] = 1.0f - (iy - fy);
     }
     __syncthreads();
-    // a thread owns (y, x, channel) positions and walks the disparities: the row part of the bilinear weights is
-    // fixed per position, the D iterations are independent (four in flight: the table look-ups and the taps are
-    // LDS round trips)
-    for (int e = threadIdx.x; e < 4 * plane; e += MID_THREADS) {
-        const int c = e & 3, yx = e >> 2, y = yx / W, x = yx - y * W;
+    // The warped right value depends on (channel, y, x - d) only: W + D - 1 bilinear samples per (channel, row) instead of
+    // W * D (round 6: the cost phase was 19 of the kernel's 56 us with one evaluation per cell -- timing-only builds: loads
+    // 6.5, costs 19.3, transform + stores 30.5, additive at one workgroup per CU).  RW [H][4][SP], SP == 8 (mod 32): the
+    // half-wave of 8 positions x 4 channels reads 32 banks.
+    const int S = W + D - 1, SP = head_rw_pitch(W, D);
+    float *RW = ty + 3 * H;
+    for (int e = threadIdx.x; e < 4 * H * S; e += MID_THREADS) {
+        const int c = e & 3, rest = e >> 2, y = rest / S, i = rest - y * S;
         const int y0 = (int)ty[3 * y], y1 = y0 + 1;
         const float wy0 = ty[3 * y + 1], wy1 = ty[3 * y + 2];
         const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
         const float *R0 = Rs + c * plane + (vy0 ? y0 : 0) * W, *R1 = Rs + c * plane + (vy1 ? y1 : 0) * W;
+        const int x0 = (int)tx[3 * i], x1 = x0 + 1;
+        const float wx0 = tx[3 * i + 1], wx1 = tx[3 * i + 2];
+        const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+        const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+        const float a00 = R0[vx0 ? x0 : 0], a01 = R0[vx1 ? x1 : 0], a10 = R1[vx0 ? x0 : 0], a11 = R1[vx1 ? x1 : 0];
+        float rr = 0.f;                                 // same tap order as grid_sample
+        if (vy0 && vx0) rr += a00 * w00;
+        if (vy0 && vx1) rr += a01 * w01;
+        if (vy1 && vx0) rr += a10 * w10;
+        if (vy1 && vx1) rr += a11 * w11;
+        RW[(y * 4 + c) * SP + i] = rr;
+    }
+    __syncthreads();
+    // a thread owns (y, x, channel) positions and walks the disparities
+    for (int e = threadIdx.x; e < 4 * plane; e += MID_THREADS) {
+        const int c = e & 3, yx = e >> 2, y = yx / W, x = yx - y * W;
         const float lv = Ls[c * plane + yx];
         float *cell = ys + (y * 4 + c) * Wp + x;        // + d * H * 4 * Wp
-        const float *t0 = tx + 3 * (x + D - 1);         // - 3 d
+        const float *rw = RW + (y * 4 + c) * SP + x + D - 1;     // - d: the sample at x - d
 #pragma unroll 4
         for (int d = 0; d < D; ++d) {
-            const int x0 = (int)t0[-3 * d], x1 = x0 + 1;
-            const float wx0 = t0[-3 * d + 1], wx1 = t0[-3 * d + 2];
-            const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
-            const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
             const float l = x >= d ? lv : 0.f;          // submodule.py:506-508
-            const float a00 = R0[vx0 ? x0 : 0], a01 = R0[vx1 ? x1 : 0], a10 = R1[vx0 ? x0 : 0], a11 = R1[vx1 ? x1 : 0];
-            float rr = 0.f;                             // same tap order as grid_sample
-            if (vy0 && vx0) rr += a00 * w00;
-            if (vy0 && vx1) rr += a01 * w01;
-            if (vy1 && vx0) rr += a10 * w10;
-            if (vy1 && vx1) rr += a11 * w11;
-            cell[d * H * 4 * Wp] = decnet_cost<CF>(l, rr);   // submodule.py:511-530
+            cell[d * H * 4 * Wp] = decnet_cost<CF>(l, rw[-d]);   // submodule.py:511-530
         }
     }
     __syncthreads();
@@ -1233,7 +1245,7 @@ bool stack_ok(int B, int D, int H, int W, int C, int variant) {
 }
 
 size_t head_lds_bytes(int D, int H, int W) {
-    return stack_lds_bytes(D, H, W) + ((size_t)8 * H * W + 3 * (W + D) + 3 * H) * 4;
+    return stack_lds_bytes(D, H, W) + ((size_t)8 * H * W + 3 * (W + D) + 3 * H + 4 * H * head_rw_pitch(W, D)) * 4;
 }
 
 // (Round 5: the stack as two half batches on two streams, shifted by half a layer so that one half's transform --
