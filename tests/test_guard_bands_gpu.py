@@ -75,3 +75,51 @@ def test_outputs_stay_inside_their_planes(B, C, H, W, D, p):
         assert bool((t[:G] == SENT).all()) and bool((t[G + n:] == SENT).all()), name + ": an INPUT's margin was written"
     # the fused call and the two separate ones agree (same kernels, unaligned planes)
     assert torch.equal(outs["fo"][1], outs["o"][1]) or float((outs["fo"][1] - outs["o"][1]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 216, 5, 9, 8), (2, 216, 20, 36, 8), (1, 24, 7, 11, 10), (2, 8, 3, 5, 3)])
+def test_stage0_entry_stays_inside_workspace_and_outputs(shape):
+    """decnet_stage0_forward_cf with a workspace of EXACTLY decnet_stage0_cf_workspace_floats floats between guard bands,
+    every cost function and every Conv3d variant (fused stack where it applies, per-layer paths elsewhere)."""
+    import ctypes
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import stage0 as o0
+    from test_stage0_gpu import load_reg
+    from decnet_amd import _lib
+    B, C, H, W, D = shape
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(C + H)
+    left = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev)
+    right = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev)
+    params = o0.random_params(C, 9)
+    reg = load_reg(C, params, dev)
+    wpre = o0.random_w_pre(C, 9).reshape(C, 2 * C).contiguous().to(dev)
+    for variant, algo in ((2, "winograd444"), (1, "winograd4"), (3, "direct")):
+        os.environ["DECNET_CONV_ALGO"] = algo
+        try:
+            P = reg.prepare(D)
+        finally:
+            del os.environ["DECNET_CONV_ALGO"]
+        sp = _lib.Stage0Params()
+        for i in range(7):
+            sp.w[i] = (P[i]["u"] if variant <= 2 else P[i]["w"]).data_ptr()
+            sp.scale[i], sp.shift[i] = P[i]["scale"].data_ptr(), P[i]["shift"].data_ptr()
+        sp.w_last, sp.scale_last, sp.shift_last = P[7]["w"].data_ptr(), P[7]["scale"], P[7]["shift"]
+        for cf in (0, 1, 2):
+            n = L.decnet_stage0_cf_workspace_floats(B, C, H, W, D, variant, cf)
+            assert n > 0
+            tw, ws = guarded(n, dev)
+            tp, pred = guarded(B * H * W, dev)
+            trg, rg = guarded(B * D * H * W, dev)
+            rc = L.decnet_stage0_forward_cf(left.data_ptr(), right.data_ptr(), ctypes.byref(sp),
+                                            wpre.data_ptr() if cf == 2 else None, ws.data_ptr(), rg.data_ptr(),
+                                            pred.data_ptr(), B, C, H, W, D, variant, cf, st)
+            assert rc == 0, (algo, cf, rc)
+            torch.cuda.synchronize()
+            assert bool((tw[:G] == SENT).all()) and bool((tw[G + n:] == SENT).all()), ("workspace overrun", algo, cf)
+            check("pred", tp, B * H * W)
+            check("reg", trg, B * D * H * W)
