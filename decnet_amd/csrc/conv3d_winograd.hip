@@ -628,9 +628,7 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
         __syncthreads();
     }
     // ---- phase 1: M -> y ----
-#ifndef MID_NO_P1
     wino_output_phase(mr, ys, g, Wp, cq, b, nts, nt, xs, scale, shift, C, relu, res_in != nullptr);
-#endif
     __syncthreads();
     if (res_out) {
         for (int i = threadIdx.x * 4; i < vol; i += MID_THREADS * 4) {
@@ -640,7 +638,6 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
     }
     // ---- phase 2: y -> V (B^T along W, H, D), two threads per (tile, channel): each keeps three of the six
     // W-transformed columns ----
-#ifndef MID_NO_P2
     const int itp = (items + 63) & ~63;                 // the half is uniform within a wave
     for (int it = threadIdx.x; it < 2 * itp; it += MID_THREADS) {
         const int half = it >= itp, id = it - half * itp;
@@ -652,7 +649,6 @@ __global__ __launch_bounds__(MID_THREADS) void wino_mid_transform(
         if (half == 0) mid_input_half<0>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
         else mid_input_half<1>(ys, vr, voff, xs, g, Wp, ch, z0, y0, x0);
     }
-#endif
 }
 
 // pitch of the warped-row table of wino_head_transform: >= W + D - 1, == 8 (mod 32)
