@@ -20,7 +20,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
 dev = torch.device("cuda:0")
-t0, bad, done = time.time(), 0, 0
+t0, bad, done, cond = time.time(), 0, 0, 0
 for seed in range(first, first + n):
     if time.time() - t0 > budget:
         break
@@ -51,10 +51,21 @@ for seed in range(first, first + n):
             continue
     tol = 2e-4 * max(1.0, float(reg_o.abs().max()))
     e_reg = float((r.cpu() - reg_o).abs().max())
-    e_pred = float((pred.cpu() - pred_o).abs().max())
-    e_mean = float((pred.cpu() - pred_o).abs().mean())
-    if not (e_reg <= tol and e_pred <= 1e-3 and e_mean < 1e-4):
+    d_pred = (pred.cpu() - pred_o).abs()
+    e_pred, e_mean = float(d_pred.max()), float(d_pred.mean())
+    # the soft-argmax is ill conditioned where the regularised volume has two distant near-equal maxima (random weights:
+    # |reg| ~ 100): d pred = sum_d p_d (d - pred) d reg_d.  A pixel beyond 1e-3 px passes only if the volume's MEASURED
+    # error explains it: |d pred| <= 1e-3 + 2 max|d reg| sum_d p_d |d - pred|   (seed 5864: two maxima 0.037 apart at
+    # d = 2 and d = 8, volume off by 1.0e-3 of 178 -> 1.5e-3 px; the torch-CPU oracle is 1.3e-4 px from float64 there)
+    p_o = torch.softmax(reg_o, dim=1)
+    sens = (p_o * (torch.arange(D, dtype=p_o.dtype).view(1, D, 1, 1) - pred_o.unsqueeze(1)).abs()).sum(1)
+    over = d_pred > 1e-3
+    pred_ok = bool((d_pred <= 1e-3 + 2.0 * e_reg * sens).all())
+    if bool(over.any()) and pred_ok:
+        cond += int(over.sum())
+    if not (e_reg <= tol and pred_ok and e_mean < 1e-4):
         bad += 1
         print("FAILED", tag, "reg %.3e (tol %.3e) pred max %.3e mean %.3e" % (e_reg, tol, e_pred, e_mean), flush=True)
-print("%d stage-0 cases (seeds %d ..), %d failed, %.0f s" % (done, first, bad, time.time() - t0))
+print("%d stage-0 cases (seeds %d ..), %d failed, %d pixels beyond 1e-3 px explained by the volume's own error at a "
+      "two-peaked pixel, %.0f s" % (done, first, bad, cond, time.time() - t0))
 sys.exit(1 if bad else 0)
