@@ -79,6 +79,33 @@ def test_e2e_against_reference_graph(cost_func):
     assert err[clean].mean() < 1e-3
 
 
+@pytest.mark.parametrize("cost_func", ["ssd", "cat"])
+def test_whole_graph_replays_as_a_hip_graph_with_every_cost_func(cost_func):
+    """The forward captured once into a HIP graph and replayed equals the eager forward bit for bit ("cor": bench.py's
+    `e2e.hip_graph.replay_equals_eager`, asserted in test_bench_gpu.py): the "cat" path launches conv_pre's two halves
+    and sets a dynamic-LDS attribute inside the capture, nothing allocates."""
+    from make_golden import E2E_KW, e2e_inputs
+    from decnet_amd.model import get_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    model = get_model(**dict(E2E_KW, cost_func=cost_func)).to(dev).eval()
+    left, right = (t.to(dev) for t in e2e_inputs())
+    with torch.no_grad():
+        want = model(left, right)[-1].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(left, right)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(left, right)[-1]
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+
+
 def test_demo_counterpart_runs_on_a_directory(tmp_path):
     """demo.py flow end to end on two synthetic pairs (one with calib.txt): PNG out, right size."""
     from PIL import Image
