@@ -262,6 +262,12 @@ def main():
                                 **stage0_case(sub, C=216, B=1, H=4, W=7, D=8, seed=7, store_params=False, cost_func=cf))
             np.savez_compressed(os.path.join(HERE, "stage0_cfg2_%s_full.npz" % cf),
                                 **stage0_full_case(sub, C=216, B=8, H=20, W=36, D=8, seed=11, cost_func=cf))
+            # config 3 (KITTI) and config 4 (Middlebury half-res: D = 10, the volume does not fit the fused head kernel's
+            # LDS, so the stand-alone volume kernel + the stack run instead)
+            np.savez_compressed(os.path.join(HERE, "stage0_cfg3_%s_full.npz" % cf),
+                                **stage0_full_case(sub, C=216, B=4, H=14, W=46, D=8, seed=12, cost_func=cf))
+            np.savez_compressed(os.path.join(HERE, "stage0_cfg4_%s_full.npz" % cf),
+                                **stage0_full_case(sub, C=216, B=1, H=38, W=56, D=10, seed=13, cost_func=cf))
             sys.path.insert(0, HERE)                   # the whole graph with the other stage-0 volume
             np.savez_compressed(os.path.join(HERE, "e2e_bc2_54x243_%s.npz" % cf), **e2e_case(cf))
         return

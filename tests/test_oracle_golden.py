@@ -88,7 +88,8 @@ def test_stage0_other_cost_functions_match_reference(golden_dir, cf):
     np.testing.assert_allclose(cv.numpy(), d["cost_vol"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(reg.numpy(), d["reg"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(pred.numpy(), d["pred"], rtol=0, atol=2e-5)
-    for name, sl in (("stage0_%s_c216.npz" % cf, None), ("stage0_cfg2_%s_full.npz" % cf, slice(2, 4))):
+    for name, sl in (("stage0_%s_c216.npz" % cf, None), ("stage0_cfg2_%s_full.npz" % cf, slice(2, 4)),
+                     ("stage0_cfg3_%s_full.npz" % cf, slice(1, 2)), ("stage0_cfg4_%s_full.npz" % cf, slice(0, 1))):
         d = _load(golden_dir, name)
         seed = int(d["param_seed"])
         params = o0.random_params(216, seed)
